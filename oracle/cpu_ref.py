@@ -1,0 +1,543 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU restatement of the SpeeChain ASR/TTS compute hot path.
+
+Every function cites the reference lines (under /root/reference/) whose arithmetic it restates.
+The functions are pure (explicit weights in, tensors out; nothing is mutated) and run on CPU in
+fp32 with stock torch ops.  They are pinned against the imported reference itself by
+``tests/golden/make_golden.py`` (run in the build container) and the committed fixtures under
+``tests/golden/``; see ``oracle/__init__.py`` for the parity status.
+
+Weights are passed as flat ``dict[str, Tensor]`` keyed exactly like the reference ``state_dict``
+(``prefix + 'k_layer.weight'`` ...), so one seeded state dict drives reference, oracle and product.
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import melscale
+
+Tensor = torch.Tensor
+
+# --------------------------------------------------------------------------------------------------
+# a14  make_mask_from_len          speechain/utilbox/train_util.py:31-75
+# --------------------------------------------------------------------------------------------------
+
+
+def make_mask_from_len(data_len: Tensor, max_len: Optional[int] = None, return_3d: bool = True) -> Tensor:
+    """Boolean padding mask: True for positions < len (train_util.py:58-71)."""
+    if max_len is None:
+        max_len = int(data_len.max())
+    mask = torch.arange(max_len)[None, :] < data_len.reshape(-1, 1).cpu()
+    return mask[:, None, :] if return_3d else mask
+
+
+# --------------------------------------------------------------------------------------------------
+# a1-a4  frontend                  speechain/module/frontend/{speech2linear,linear2mel,speech2mel}.py
+# --------------------------------------------------------------------------------------------------
+
+
+def secs_to_samples(value, sr: int) -> int:
+    """float seconds -> samples by truncation (speech2linear.py:85-90)."""
+    return int(value * sr) if isinstance(value, float) else value
+
+
+def preemphasis(wave: Tensor, wave_len: Tensor, coef: float) -> Tensor:
+    """y[n] = x[n] - coef*x[n-1] (x[-1]=0), then y[n >= len] = 0 (speech2linear.py:167-173).
+
+    wave: (B, T) f32.  The reference evaluates it as a 2-tap cross-correlation with taps [-coef, 1].
+    """
+    prev = F.pad(wave, (1, 0))[:, :-1]
+    taps = torch.tensor([-coef, 1.0], dtype=wave.dtype)
+    out = prev * taps[0] + wave * taps[1]
+    idx = torch.arange(wave.size(1))[None, :]
+    return out.masked_fill(idx >= wave_len.reshape(-1, 1), 0.0)
+
+
+def stft_frames(wave: Tensor, n_fft: int, hop: int, win_length: int, window: Tensor, center: bool = True) -> Tensor:
+    """Explicit framing restatement of torch.stft's semantics used at speech2linear.py:198.
+
+    center=True reflect-pads the *batch tensor* by n_fft//2 on both sides (so a short utterance sees
+    its own zero padding, not a reflection, at its right edge); the window is zero-padded centrally to
+    n_fft when win_length < n_fft.  Returns windowed frames (B, T_frames, n_fft).
+    """
+    if center:
+        wave = F.pad(wave[:, None, :], (n_fft // 2, n_fft // 2), mode="reflect")[:, 0]
+    if win_length < n_fft:
+        left = (n_fft - win_length) // 2
+        window = F.pad(window, (left, n_fft - win_length - left))
+    return wave.unfold(-1, n_fft, hop) * window
+
+
+def stft_power_explicit(wave: Tensor, n_fft: int, hop: int, win_length: int, window: Tensor, center: bool = True,
+                        dtype=torch.float64) -> Tensor:
+    """|rFFT(frames)|^2 in ``dtype`` -- an independent definition of speech2linear.py:198,214."""
+    frames = stft_frames(wave.to(dtype), n_fft, hop, win_length, window.to(dtype), center)
+    spec = torch.fft.rfft(frames, n=n_fft, dim=-1)
+    return spec.real ** 2 + spec.imag ** 2
+
+
+def stft_power(wave: Tensor, n_fft: int, hop: int, win_length: int, window: Tensor, center: bool = True) -> Tensor:
+    """(B, T_frames, n_fft//2+1) power via the stock op the reference calls (speech2linear.py:198,214)."""
+    spec = torch.stft(wave, n_fft=n_fft, hop_length=hop, win_length=win_length, window=window, center=center,
+                      normalized=False, onesided=True, return_complex=True).transpose(1, 2)
+    return spec.real ** 2 + spec.imag ** 2
+
+
+def stft_feat_len(wave_len: Tensor, n_fft: int, hop: int, center: bool = True) -> Tensor:
+    """(len + 2*(n_fft//2) - n_fft)//hop + 1 (speech2linear.py:201-212); does NOT mutate its input."""
+    padded = wave_len + 2 * (n_fft // 2) if center else wave_len
+    return torch.div(padded - n_fft, hop, rounding_mode="floor") + 1
+
+
+def speech2linear(wave: Tensor, wave_len: Tensor, *, hop_length, win_length, sr: int = 16000, n_fft: int = None,
+                  preemph: float = None, window: str = "hann", center: bool = True, mag_spec: bool = False,
+                  return_energy: bool = False, clamp: float = 1e-10, logging: bool = False,
+                  log_base: float = None, explicit: bool = False):
+    """Speech2LinearSpec.forward (speech2linear.py:142-250), pre_stft_norm=None, normalized=False, onesided."""
+    hop, win = secs_to_samples(hop_length, sr), secs_to_samples(win_length, sr)
+    n_fft = win if n_fft is None else n_fft
+    if wave.dim() == 3:
+        wave = wave.squeeze(-1)
+    if preemph is not None:
+        wave = preemphasis(wave, wave_len, preemph)
+    win_t = getattr(torch, f"{window}_window")(win, dtype=wave.dtype)
+    if explicit:
+        power = stft_power_explicit(wave, n_fft, hop, win, win_t, center, dtype=wave.dtype)
+    else:
+        power = stft_power(wave, n_fft, hop, win, win_t, center)
+    feat_len = stft_feat_len(wave_len, n_fft, hop, center)
+    frame_idx = torch.arange(power.size(1))[None, :]
+    pad = frame_idx >= feat_len.reshape(-1, 1)
+    energy = None
+    if return_energy:
+        energy = torch.sqrt(torch.clamp(power.sum(dim=-1), min=1e-10)).masked_fill(pad, 0.0)
+    power = power.masked_fill(pad[:, :, None], 0.0)
+    feat = torch.sqrt(power) if mag_spec else power
+    if logging:
+        feat = torch.clamp(feat, min=clamp).log()
+        if log_base is not None:
+            feat = feat / math.log(log_base)
+    if return_energy:
+        return feat, feat_len, energy, feat_len
+    return feat, feat_len
+
+
+def mel_matrix(n_fft: int, n_mels: int, sr: int = 16000, fmin: float = 0.0, fmax: float = None,
+               mel_scale: str = "slaney", mel_norm: bool = True) -> Tensor:
+    """(n_mels, n_fft//2+1) weight of the bias-free Linear at linear2mel.py:135-155."""
+    fmax = fmax if fmax is not None else sr // 2
+    fb = melscale.melscale_fbanks(n_fft // 2 + 1, fmin, fmax, n_mels, sr, norm="slaney" if mel_norm else None,
+                                  mel_scale=mel_scale)
+    return torch.from_numpy(fb.T.copy())
+
+
+def linear2mel(feat: Tensor, mel_w: Tensor, clamp: float = 1e-10, logging: bool = True, log_base: float = 10.0) -> Tensor:
+    """LinearSpec2MelSpec.forward (linear2mel.py:163-189)."""
+    feat = F.linear(feat, mel_w)
+    if logging:
+        feat = torch.clamp(feat, min=clamp).log()
+        if log_base is not None:
+            feat = feat / math.log(log_base)
+    return feat
+
+
+def delta_features(feat: Tensor, delta_order: int, delta_N: int = 2) -> Tensor:
+    """DeltaFeature.forward (delta_feat.py:57-81): regression deltas with replicate padding, concatenated."""
+    kernel = torch.arange(-delta_N, delta_N + 1, dtype=feat.dtype) / (2 * sum(i * i for i in range(1, delta_N + 1)))
+    outs, cur = [feat], feat
+    for _ in range(delta_order):
+        x = F.pad(cur[:, None], (0, 0, delta_N, delta_N), mode="replicate")
+        cur = F.conv2d(x, kernel.reshape(1, 1, -1, 1))[:, 0]
+        outs.append(cur)
+    return torch.cat(outs, dim=-1)
+
+
+def speech2mel(wave: Tensor, wave_len: Tensor, *, n_mels: int, hop_length, win_length, n_fft: int = None,
+               sr: int = 16000, preemphasis: float = None, window: str = "hann", center: bool = True,
+               mag_spec: bool = False, return_energy: bool = False, fmin: float = 0.0, fmax: float = None,
+               clamp: float = 1e-10, logging: bool = True, log_base: float = 10.0, mel_scale: str = "slaney",
+               mel_norm: bool = True, mel_w: Tensor = None, explicit: bool = False):
+    """Speech2MelSpec.forward (speech2mel.py:158-189) = a2 -> a3 (kwargs named as the reference's)."""
+    hop, win = secs_to_samples(hop_length, sr), secs_to_samples(win_length, sr)
+    n_fft = win if n_fft is None else n_fft
+    out = speech2linear(wave, wave_len, hop_length=hop, win_length=win, sr=sr, n_fft=n_fft, preemph=preemphasis,
+                        window=window, center=center, mag_spec=mag_spec, return_energy=return_energy, logging=False,
+                        explicit=explicit)
+    if mel_w is None:
+        mel_w = mel_matrix(n_fft, n_mels, sr, fmin, fmax, mel_scale, mel_norm)
+    feat = linear2mel(out[0], mel_w, clamp, logging, log_base)
+    if return_energy:
+        return feat, out[1], out[2], out[3]
+    return feat, out[1]
+
+
+# --------------------------------------------------------------------------------------------------
+# a5  SpecAugment                  speechain/module/augment/specaug.py:19-206
+# --------------------------------------------------------------------------------------------------
+
+
+def specaug_draw(feat_len: Tensor, batch: int, feat_dim: int, *, time_warp: bool = True, time_warp_window: int = 5,
+                 freq_mask: bool = True, freq_mask_width=30, freq_mask_num: int = 2, time_mask: bool = True,
+                 time_mask_width=0.05, time_mask_num: int = 2, device="cpu") -> Dict:
+    """All random integers of one SpecAugment.forward call, in the reference's draw order.
+
+    warp_center, warp_pos on the default CPU generator (specaug.py:98-108); freq mask_len then mask_pos
+    (:145-158) and time mask_len then mask_pos (:178-191) on ``device``'s generator.
+    """
+    tmin = int(feat_len.min())
+    d: Dict = dict(time_minlen=tmin, time_maxlen=int(feat_len.max()), warp_center=None, warp_pos=None,
+                   freq_len=None, freq_pos=None, time_len=None, time_pos=None)
+    W = time_warp_window
+    if time_warp and tmin > 2 * W + 1:
+        d["warp_center"] = int(torch.randint(low=W + 1, high=tmin - W, size=(1,))[0])
+        d["warp_pos"] = int(torch.randint(low=d["warp_center"] - W, high=d["warp_center"] + W, size=(1,))[0])
+    if freq_mask:
+        fw = [0, freq_mask_width] if isinstance(freq_mask_width, int) else list(freq_mask_width)
+        d["freq_len"] = torch.randint(fw[0], fw[1] + 1, size=(batch, freq_mask_num), device=device)
+        d["freq_pos"] = torch.randint(0, max(1, feat_dim - int(d["freq_len"].max())), size=(batch, freq_mask_num),
+                                      device=device)
+    if time_mask:
+        tw = [0, time_mask_width] if isinstance(time_mask_width, (int, float)) else list(time_mask_width)
+        lo, hi = tw
+        lo = int(lo * tmin) if isinstance(lo, float) else lo
+        hi = int(hi * tmin) if isinstance(hi, float) else hi
+        hi = min(hi, tmin)
+        d["time_len"] = torch.randint(lo, hi + 1, size=(batch, time_mask_num), device=device)
+        d["time_pos"] = torch.randint(0, max(1, tmin - int(d["time_len"].max())), size=(batch, time_mask_num),
+                                      device=device)
+    return d
+
+
+def _keys_cubic(t: Tensor, A: float = -0.75) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """The four Keys cubic-convolution taps used by aten's bicubic upsampling."""
+    def inner(x):  # |x| <= 1
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+    def outer(x):  # 1 < |x| < 2
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return outer(t + 1), inner(t), inner(1 - t), outer(2 - t)
+
+
+def time_resample_cubic(seg: Tensor, out_len: int) -> Tensor:
+    """1-D restatement of F.interpolate(seg[:,None], size=(out_len, F), mode='bicubic', align_corners=True)
+    (specaug.py:111-122) for seg (B, T_in, F): the F axis keeps its size so only T is resampled.
+    src = dst * fp32((T_in-1)/(out_len-1)); 4 taps, border-clamped indices, A=-0.75."""
+    t_in = seg.size(1)
+    scale = torch.tensor((t_in - 1) / (out_len - 1) if out_len > 1 else 0.0, dtype=torch.float32)
+    src = torch.arange(out_len, dtype=torch.float32) * scale
+    i0 = torch.floor(src)
+    lam = (src - i0).clamp(0.0, 1.0)
+    i0 = i0.long()
+    w = _keys_cubic(lam)
+    out = torch.zeros(seg.size(0), out_len, seg.size(2), dtype=seg.dtype)
+    for j in range(4):
+        idx = (i0 - 1 + j).clamp(0, t_in - 1)
+        out = out + seg[:, idx, :] * w[j][None, :, None]
+    return out
+
+
+def specaug_apply(feat: Tensor, feat_len: Tensor, draws: Dict, *, time_warp_mode: str = "bicubic",
+                  feat_norm: bool = True, explicit_warp: bool = False) -> Tensor:
+    """SpecAugment.forward given its random integers (specaug.py:86-204).  Returns a new tensor."""
+    feat = feat.clone()
+    B, T, Fd = feat.shape
+    tmin = draws["time_minlen"]
+    if draws["warp_center"] is not None:
+        c, p = draws["warp_center"], draws["warp_pos"]
+        if explicit_warp:
+            left = time_resample_cubic(feat[:, :c], p)
+            right = time_resample_cubic(feat[:, c:tmin], tmin - p)
+        else:
+            x = feat[:, None]
+            left = F.interpolate(x[:, :, :c], size=(p, Fd), mode=time_warp_mode, align_corners=True)[:, 0]
+            right = F.interpolate(x[:, :, c:tmin], size=(tmin - p, Fd), mode=time_warp_mode, align_corners=True)[:, 0]
+        feat[:, :p] = left
+        feat[:, p:tmin] = right
+    mask = specaug_mask(draws, B, T, Fd)
+    if mask is not None:
+        fill = 0.0 if feat_norm else feat.mean()
+        feat = feat.masked_fill(mask, fill)
+    return feat
+
+
+def specaug_mask(draws: Dict, B: int, T: int, Fd: int) -> Optional[Tensor]:
+    """The (B, T, F) boolean union of frequency and time ranges (specaug.py:160-199)."""
+    mask = None
+    if draws["freq_len"] is not None:
+        ln, ps = draws["freq_len"].cpu()[:, :, None], draws["freq_pos"].cpu()[:, :, None]
+        ax = torch.arange(Fd)[None, None, :]
+        mask = ((ps <= ax) & (ax < ps + ln)).any(dim=1, keepdim=True)
+    if draws["time_len"] is not None:
+        ln, ps = draws["time_len"].cpu()[:, None, :], draws["time_pos"].cpu()[:, None, :]
+        ax = torch.arange(T)[None, :, None]
+        tm = ((ps <= ax) & (ax < ps + ln)).any(dim=-1, keepdim=True)
+        mask = tm if mask is None else torch.logical_or(mask, tm)
+    if mask is not None:
+        mask = mask.expand(B, T, Fd)
+    return mask
+
+
+# --------------------------------------------------------------------------------------------------
+# a6  PositionalEncoding           speechain/module/transformer/pos_enc.py:24-188
+# --------------------------------------------------------------------------------------------------
+
+
+def posenc_table(max_len: int, d_model: int, posenc_type: str = "mix") -> Tensor:
+    """(1, max_len, d) sinusoid table (pos_enc.py:115-146)."""
+    pos = torch.arange(0, max_len, dtype=torch.float)[:, None]
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float) * (math.log(10000.0) / d_model))
+    tab = torch.zeros(max_len, d_model)
+    if posenc_type == "mix":
+        tab[:, 0::2] = torch.sin(pos / div)
+        tab[:, 1::2] = torch.cos(pos / div)
+    else:
+        div2 = torch.exp(torch.arange(d_model, 2 * d_model, 2, dtype=torch.float) * (math.log(10000.0) / d_model))
+        tab[:, : d_model // 2] = torch.sin(pos / div)
+        tab[:, d_model // 2:] = torch.cos(pos / div2)
+    return tab[None]
+
+
+def posenc_forward(x: Tensor, P: Dict[str, Tensor], prefix: str, d_model: int, emb_scale: bool = False) -> Tensor:
+    """PositionalEncoding.forward in eval mode (pos_enc.py:148-182): [LN eps 1e-5] -> [*sqrt(d)] -> + table*[alpha]."""
+    if prefix + "emb_layernorm.weight" in P:
+        x = F.layer_norm(x, (d_model,), P[prefix + "emb_layernorm.weight"], P[prefix + "emb_layernorm.bias"], 1e-5)
+    if emb_scale:
+        x = x * math.sqrt(d_model)
+    tab = P[prefix + "posenc"][:, : x.size(1)]
+    if prefix + "alpha" in P:
+        tab = tab * P[prefix + "alpha"]
+    return x + tab
+
+
+# --------------------------------------------------------------------------------------------------
+# a7-a10  attention / FFN / layers / stacks      speechain/module/transformer/*.py
+# --------------------------------------------------------------------------------------------------
+
+
+def mha(k: Tensor, v: Tensor, q: Tensor, mask: Optional[Tensor], P: Dict[str, Tensor], prefix: str, num_heads: int,
+        scale_dp_by_head: bool = False) -> Tuple[Tensor, Tensor]:
+    """MultiHeadedAttention.forward, dropout off (attention.py:67-133).  Argument order (k, v, q, mask);
+    mask is (B,1,Tk) or (B,Tq,Tk) bool with True = attend.  Returns (out (B,Tq,d), probs (B,H,Tq,Tk))."""
+    B, d = k.size(0), q.size(-1)
+    dh = d // num_heads
+    def split(x, name):
+        return F.linear(x, P[prefix + name + ".weight"], P[prefix + name + ".bias"]).view(B, -1, num_heads, dh).transpose(1, 2)
+    kh, vh, qh = split(k, "k_layer"), split(v, "v_layer"), split(q, "q_layer")
+    scale = 1 / math.sqrt(dh) if scale_dp_by_head else 1 / math.sqrt(d)
+    scores = torch.matmul(qh, kh.transpose(2, 3)) * scale
+    if mask is not None:
+        scores = scores.masked_fill(~mask[:, None], float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(probs, vh).transpose(1, 2).contiguous().view(B, -1, d)
+    return F.linear(ctx, P[prefix + "output_layer.weight"], P[prefix + "output_layer.bias"]), probs
+
+
+def _activation(name: str):
+    return getattr(torch.nn, name)()
+
+
+def ffn(x: Tensor, P: Dict[str, Tensor], prefix: str, activation: str = "ReLU", fdfwd_type: str = "linear") -> Tensor:
+    """PositionwiseFeedForward.forward, dropout off (feed_forward.py:77-106).  'conv' = Conv1d k odd, 'same'
+    zero padding, stride 1 over time (prenet/conv1d.py:73-90), weights ``in_layer.conv_lyr.weight`` (f,d,k)."""
+    act = _activation(activation)
+    if fdfwd_type == "linear":
+        h = act(F.linear(x, P[prefix + "in_layer.weight"], P[prefix + "in_layer.bias"]))
+        return F.linear(h, P[prefix + "out_layer.weight"], P[prefix + "out_layer.bias"])
+    w1, w2 = P[prefix + "in_layer.conv_lyr.weight"], P[prefix + "out_layer.conv_lyr.weight"]
+    h = act(F.conv1d(x.transpose(1, 2), w1, P[prefix + "in_layer.conv_lyr.bias"], padding=(w1.size(-1) - 1) // 2))
+    return F.conv1d(h, w2, P[prefix + "out_layer.conv_lyr.bias"], padding=(w2.size(-1) - 1) // 2).transpose(1, 2)
+
+
+def _ln(x, P, name, eps=1e-6):
+    return F.layer_norm(x, (x.size(-1),), P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def encoder_layer(src: Tensor, mask: Tensor, P, prefix: str, num_heads: int, *, scale_dp_by_head=False,
+                  activation="ReLU", fdfwd_type="linear", layernorm_first=True) -> Tuple[Tensor, Tensor]:
+    """TransformerEncoderLayer.forward, dropout off (encoder.py:100-143); LN eps 1e-6 (:97-98)."""
+    x = _ln(src, P, prefix + "att_layernorm") if layernorm_first else src
+    att, probs = mha(x, x, x, mask, P, prefix + "multihead_att.", num_heads, scale_dp_by_head)
+    y = att + src
+    if not layernorm_first:
+        y = _ln(y, P, prefix + "att_layernorm")
+    z = _ln(y, P, prefix + "fdfwd_layernorm") if layernorm_first else y
+    out = ffn(z, P, prefix + "feed_forward.", activation, fdfwd_type) + y
+    if not layernorm_first:
+        out = _ln(out, P, prefix + "fdfwd_layernorm")
+    return out, probs
+
+
+def subsequent_mask(batch: int, n: int) -> Tensor:
+    """Lower-triangular (incl. diagonal) True mask (encoder.py:294-308)."""
+    return ~torch.triu(torch.ones(batch, n, n, dtype=torch.bool), diagonal=1)
+
+
+def transformer_encoder(src: Tensor, mask: Tensor, P, prefix: str, *, num_layers: int, num_heads: int, d_model: int,
+                        emb_scale=False, scale_dp_by_head=False, activation="ReLU", fdfwd_type="linear",
+                        layernorm_first=True, uni_direction=False):
+    """TransformerEncoder.forward, dropout off (encoder.py:310-349) -> (out, mask, attmat[L], hidden[L])."""
+    x = posenc_forward(src, P, prefix + "posenc.", d_model, emb_scale)
+    if uni_direction:
+        B, _, T = mask.shape
+        mask = torch.logical_and(mask.repeat(1, T, 1), subsequent_mask(B, T))
+    attmat, hidden = [], []
+    for l in range(num_layers):
+        x, a = encoder_layer(x, mask, P, f"{prefix}trfm_layers.{l}.", num_heads, scale_dp_by_head=scale_dp_by_head,
+                             activation=activation, fdfwd_type=fdfwd_type, layernorm_first=layernorm_first)
+        attmat.append(a)
+        hidden.append(x.clone())
+    if layernorm_first:
+        x = _ln(x, P, prefix + "layernorm")
+    return x, mask, attmat, hidden
+
+
+def decoder_layer(tgt: Tensor, src: Tensor, tgt_mask: Tensor, src_mask: Tensor, P, prefix: str, num_heads: int, *,
+                  scale_dp_by_head=False, activation="ReLU", layernorm_first=True):
+    """TransformerDecoderLayer.forward, dropout off (decoder.py:94-175).  enc-dec attention never scales by
+    head (decoder.py:76-78)."""
+    x = _ln(tgt, P, prefix + "self_att_ln") if layernorm_first else tgt
+    sa, sp = mha(x, x, x, tgt_mask, P, prefix + "self_att.", num_heads, scale_dp_by_head)
+    y = sa + tgt
+    if not layernorm_first:
+        y = _ln(y, P, prefix + "self_att_ln")
+    yn = _ln(y, P, prefix + "encdec_att_ln") if layernorm_first else y
+    ea, ep = mha(src, src, yn, src_mask, P, prefix + "encdec_att.", num_heads, False)
+    z = ea + y
+    if not layernorm_first:
+        z = _ln(z, P, prefix + "encdec_att_ln")
+    zn = _ln(z, P, prefix + "fdfwd_ln") if layernorm_first else z
+    out = ffn(zn, P, prefix + "feed_forward.", activation, "linear") + z
+    if not layernorm_first:
+        out = _ln(out, P, prefix + "fdfwd_ln")
+    return out, sp, ep
+
+
+def transformer_decoder(tgt: Tensor, src: Tensor, tgt_mask: Tensor, src_mask: Tensor, P, prefix: str, *,
+                        num_layers: int, num_heads: int, d_model: int, emb_scale=True, scale_dp_by_head=False,
+                        activation="ReLU", layernorm_first=True):
+    """TransformerDecoder.forward, dropout off (decoder.py:307-362).  Decoder *layers* are always built with
+    the layer default layernorm_first=True (decoder.py:271-285); ``layernorm_first`` only gates the final LN."""
+    x = posenc_forward(tgt, P, prefix + "posenc.", d_model, emb_scale)
+    B, _, L = tgt_mask.shape
+    m = torch.logical_and(tgt_mask.repeat(1, L, 1), subsequent_mask(B, L))
+    self_att, encdec_att, hidden = [], [], []
+    for l in range(num_layers):
+        x, a, e = decoder_layer(x, src, m, src_mask, P, f"{prefix}trfm_layers.{l}.", num_heads,
+                                scale_dp_by_head=scale_dp_by_head, activation=activation, layernorm_first=True)
+        self_att.append(a)
+        encdec_att.append(e)
+        hidden.append(x.clone())
+    if layernorm_first:
+        x = _ln(x, P, prefix + "layernorm")
+    return x, self_att, encdec_att, hidden
+
+
+# --------------------------------------------------------------------------------------------------
+# a11  TokenPostnet                speechain/module/postnet/token.py:40-49
+# --------------------------------------------------------------------------------------------------
+
+
+def token_postnet(x: Tensor, P, prefix: str) -> Tensor:
+    return F.linear(x, P[prefix + "linear.weight"], P[prefix + "linear.bias"])
+
+
+# --------------------------------------------------------------------------------------------------
+# a12  CTCLoss                     speechain/criterion/ctc.py:25-66
+# --------------------------------------------------------------------------------------------------
+
+
+def ctc_loss(ctc_logits: Tensor, enc_len: Tensor, text: Tensor, text_len: Tensor, blank: int = 0,
+             zero_infinity: bool = True) -> Tensor:
+    """log_softmax over V, strip the leading/trailing <sos/eos> of ``text``, per-utterance CTC negative
+    log-likelihood (NOT length-normalised), zero_infinity, mean over the batch."""
+    lp = ctc_logits.transpose(0, 1).log_softmax(dim=-1)
+    tgt, tgt_len = text[:, 1:-1], text_len - 2
+    flat = torch.cat([tgt[i, : tgt_len[i]] for i in range(tgt.size(0))])
+    loss = F.ctc_loss(lp, flat, enc_len, tgt_len, blank=blank, reduction="none", zero_infinity=zero_infinity)
+    return loss.mean()
+
+
+def ctc_nll_explicit(log_probs: Tensor, target: Sequence[int], blank: int = 0) -> float:
+    """Independent alpha recursion for ONE utterance (log_probs (T, V) float64), Graves et al. 2006.
+    Used to pin ``ctc_loss`` on small cases."""
+    ext = [blank]
+    for s in target:
+        ext += [int(s), blank]
+    S, T = len(ext), log_probs.size(0)
+    neg = float("-inf")
+    alpha = [neg] * S
+    alpha[0] = float(log_probs[0, blank])
+    if S > 1:
+        alpha[1] = float(log_probs[0, ext[1]])
+    def lse(*xs):
+        m = max(xs)
+        return m if m == neg else m + math.log(sum(math.exp(x - m) for x in xs))
+    for t in range(1, T):
+        new = [neg] * S
+        for s in range(S):
+            terms = [alpha[s]]
+            if s >= 1:
+                terms.append(alpha[s - 1])
+            if s >= 2 and ext[s] != blank and ext[s] != ext[s - 2]:
+                terms.append(alpha[s - 2])
+            new[s] = lse(*terms) + float(log_probs[t, ext[s]])
+        alpha = new
+    return -(lse(alpha[S - 1], alpha[S - 2]) if S > 1 else alpha[0])
+
+
+# --------------------------------------------------------------------------------------------------
+# a13  CrossEntropy                speechain/criterion/cross_entropy.py:97-212
+# --------------------------------------------------------------------------------------------------
+
+
+def cross_entropy(logits: Tensor, text: Tensor, text_len: Tensor, label_smoothing: float = 0.0,
+                  length_normalized: bool = False, temperature: float = 1.0) -> Tensor:
+    """Label-smoothed, length-masked CE (confid_threshold=0, no token weights).  When ``text`` carries a
+    leading <sos/eos> (one longer than logits) it is dropped and lengths shrink by one (:115-125)."""
+    if logits.size(1) == text.size(1) - 1:
+        text, text_len = text[:, 1:], text_len - 1
+    B, L, V = logits.shape
+    lp = torch.log_softmax(logits.reshape(B * L, V) / temperature, dim=-1)
+    lp_t = lp.gather(1, text.reshape(-1, 1)).squeeze(-1)
+    if label_smoothing > 0:
+        tok = lp_t * (1 - label_smoothing) + (lp * (label_smoothing / V)).sum(dim=1)
+    else:
+        tok = lp_t
+    valid = make_mask_from_len(text_len, max_len=L, return_3d=False).reshape(-1)
+    sent = tok.masked_fill(~valid, 0.0).reshape(B, L).sum(dim=-1)
+    if length_normalized:
+        sent = sent / (text_len + 1e-10)
+    return -sent.mean()
+
+
+# --------------------------------------------------------------------------------------------------
+# a-harness  the callers' sequencing, restated (module/encoder/asr.py:103-131,
+#            module/decoder/ar_asr.py:49-78, model/ar_asr.py:386-388,453-458,550)
+# --------------------------------------------------------------------------------------------------
+
+
+def asr_forward_loss(feat: Tensor, feat_len: Tensor, text: Tensor, text_len: Tensor, P: Dict[str, Tensor], cfg: Dict):
+    """Log-mel (already subsampled to the encoder rate) -> encoder -> decoder -> heads -> 0.7 CE + 0.3 CTC.
+
+    ``feat`` (B, T', d_model) is the encoder input (the Conv2dPrenet is outside the named path);
+    ``text`` (B, L) starts and ends with <sos/eos>; the decoder consumes text[:, :-1] (model/ar_asr.py:386-388).
+    Weight prefixes: 'encoder.', 'embed.weight', 'decoder.', 'postnet.', 'ctc_layer.'.
+    """
+    enc_mask = make_mask_from_len(feat_len, max_len=feat.size(1))
+    enc, _, _, _ = transformer_encoder(feat, enc_mask, P, "encoder.", num_layers=cfg["enc_layers"],
+                                       num_heads=cfg["num_heads"], d_model=cfg["d_model"],
+                                       activation=cfg["activation"], emb_scale=False)
+    dec_in, dec_len = text.clone(), text_len - 1
+    dec_in[torch.arange(text.size(0)), text_len - 1] = 0  # each sentence's trailing <sos/eos> -> padding idx
+    dec_in = dec_in[:, :-1]
+    emb = F.embedding(dec_in, P["embed.weight"], padding_idx=0)
+    tmask = make_mask_from_len(dec_len, max_len=dec_in.size(1))
+    dec, _, _, _ = transformer_decoder(emb, enc, tmask, enc_mask, P, "decoder.", num_layers=cfg["dec_layers"],
+                                       num_heads=cfg["num_heads"], d_model=cfg["d_model"],
+                                       activation=cfg["activation"], emb_scale=False)
+    logits = token_postnet(dec, P, "postnet.")
+    ctc_logits = token_postnet(enc, P, "ctc_layer.")
+    ce = cross_entropy(logits, text, text_len, label_smoothing=cfg.get("label_smoothing", 0.0))
+    ctc = ctc_loss(ctc_logits, feat_len, text, text_len)
+    w = cfg.get("ctc_weight", 0.3)
+    return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=(1 - w) * ce + w * ctc)

@@ -1,0 +1,409 @@
+"""Generates the golden fixtures in this directory by IMPORTING AND RUNNING the reference modules.
+
+Run in the build container only (needs /root/reference, never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is stubbed and why:
+  * ``torchaudio`` is absent from the image; the reference only needs
+    ``torchaudio.functional.melscale_fbanks`` on the forward path (linear2mel.py:135).  A stub module
+    provides it from ``oracle/melscale.py`` (restatement of torchaudio's published algorithm) -> the
+    mel matrix values are "parity unpinned"; everything downstream of them is the reference's own code.
+  * ``GPUtil`` (only imported by utilbox/import_util.py) is stubbed with an empty module.
+
+Outputs are data only (inputs, seeds' products, expected outputs) as ``.npz``; no reference text.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from oracle import melscale  # noqa: E402
+
+# ---- stubs -------------------------------------------------------------------------------------
+ta = types.ModuleType("torchaudio")
+ta.functional = types.ModuleType("torchaudio.functional")
+ta.transforms = types.ModuleType("torchaudio.transforms")
+
+
+def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    return torch.from_numpy(melscale.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm, mel_scale))
+
+
+ta.functional.melscale_fbanks = _melscale_fbanks
+sys.modules["torchaudio"] = ta
+sys.modules["torchaudio.functional"] = ta.functional
+sys.modules["torchaudio.transforms"] = ta.transforms
+gp = types.ModuleType("GPUtil")
+gp.GPU = object
+gp.getGPUs = lambda: []
+sys.modules["GPUtil"] = gp
+
+from speechain.module.frontend.speech2mel import Speech2MelSpec  # noqa: E402
+from speechain.module.frontend.speech2linear import Speech2LinearSpec  # noqa: E402
+from speechain.module.augment.specaug import SpecAugment  # noqa: E402
+from speechain.module.transformer.pos_enc import PositionalEncoding  # noqa: E402
+from speechain.module.transformer.attention import MultiHeadedAttention  # noqa: E402
+from speechain.module.transformer.feed_forward import PositionwiseFeedForward  # noqa: E402
+from speechain.module.transformer.encoder import TransformerEncoder, TransformerEncoderLayer  # noqa: E402
+from speechain.module.transformer.decoder import TransformerDecoder, TransformerDecoderLayer  # noqa: E402
+from speechain.module.postnet.token import TokenPostnet  # noqa: E402
+from speechain.module.prenet.embed import EmbedPrenet  # noqa: E402
+from speechain.criterion.cross_entropy import CrossEntropy  # noqa: E402
+from speechain.criterion.ctc import CTCLoss  # noqa: E402
+from speechain.utilbox.train_util import make_mask_from_len  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _compact(a):
+    """float32 arrays that are exactly representable in float16 (the seeded weights) are stored as float16."""
+    if a.dtype == np.float32 and a.size > 64:
+        h = a.astype(np.float16)
+        if np.array_equal(h.astype(np.float32), a):
+            return h
+    return a
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: _compact(npy(v)) for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  keys={len(arrays)}")
+
+
+def seeded_state(module, seed, scale=None):
+    """Deterministic re-init of every parameter (buffers untouched): N(0, std) with xavier-like std."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() > 1:
+                std = (2.0 / (p.size(0) + p.size(1))) ** 0.5 if scale is None else scale
+                p.copy_((torch.randn(p.shape, generator=g) * std).half().float())  # fp16-exact: compact fixture
+            elif n.endswith("alpha"):
+                p.copy_(torch.tensor(1.25))
+            elif "layernorm" in n or n.endswith("_ln.weight") or n.endswith("_ln.bias"):
+                base = 1.0 if n.endswith("weight") else 0.0
+                p.copy_(base + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    return {k: v.clone() for k, v in module.state_dict().items()}
+
+
+# ---- G1 frontend ---------------------------------------------------------------------------------
+
+def g1_frontend():
+    g = torch.Generator().manual_seed(101)
+    lens = torch.tensor([24000, 19999, 16000, 8001])
+    wave = torch.randn(4, 24000, 1, generator=g) * 0.1
+    # a decaying-spectrum utterance (tests accuracy on low-power bins) and a silent tail
+    t = torch.arange(24000) / 16000.0
+    wave[2, :, 0] = 0.3 * torch.sin(2 * np.pi * 220 * t) + 0.01 * torch.sin(2 * np.pi * 3000 * t) + 1e-4 * wave[2, :, 0]
+    for i, l in enumerate(lens):
+        wave[i, l:] = 0.0
+    out = dict(wave=wave, wave_len=lens)
+    # ASR preset (config/feat/log_mel/conventional_asr.yaml + recipe frontend conf)
+    asr = Speech2MelSpec(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025, n_mels=80)
+    feat, feat_len = asr(wave.clone(), lens.clone())
+    out.update(asr_logmel=feat, asr_len=feat_len, asr_melw=asr.linear2mel.mel_fbanks.weight)
+    lin = Speech2LinearSpec(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025)
+    lfeat, _ = lin(wave.clone(), lens.clone())
+    out.update(asr_power=lfeat[:2, :40])  # a slice keeps the fixture small
+    # TTS preset (recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:206-217)
+    tts = Speech2MelSpec(sr=22050, hop_length=256, win_length=1024, n_fft=1024, n_mels=80, fmin=0, fmax=8000,
+                         mag_spec=True, return_energy=True, clamp=1e-5, log_base=None)
+    f2, l2, e2, el2 = tts(wave[:3].clone(), lens[:3].clone())
+    out.update(tts_logmel=f2, tts_len=l2, tts_energy=e2, tts_melw=tts.linear2mel.mel_fbanks.weight)
+    # no-preemphasis, non-default n_fft > win (central window padding), htk / no norm, log base e
+    odd = Speech2MelSpec(sr=16000, hop_length=128, win_length=400, n_fft=512, n_mels=40, mel_scale="htk",
+                         mel_norm=False, log_base=None)
+    f3, l3 = odd(wave[:2].clone(), lens[:2].clone())
+    out.update(odd_logmel=f3, odd_len=l3, odd_melw=odd.linear2mel.mel_fbanks.weight)
+    save("g1_frontend", **out)
+
+
+# ---- G2 SpecAugment ------------------------------------------------------------------------------
+
+def _capture_randint():
+    """Wraps torch.randint to record every draw the reference makes, in order."""
+    rec = []
+    orig = torch.randint
+
+    def wrapped(*a, **k):
+        r = orig(*a, **k)
+        rec.append(r.clone())
+        return r
+
+    return rec, orig, wrapped
+
+
+def g2_specaug():
+    g = torch.Generator().manual_seed(202)
+    feat = torch.randn(3, 120, 80, generator=g)
+    feat_len = torch.tensor([120, 97, 64])
+    for i, l in enumerate(feat_len):
+        feat[i, l:] = 0.0
+    out = dict(feat=feat, feat_len=feat_len)
+    cases = dict(
+        recipe=dict(freq_mask_width=15, freq_mask_num=4, time_mask_width=0.05, time_mask_num=5),
+        default=dict(),
+        nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
+        warponly=dict(freq_mask=False, time_mask=False),
+    )
+    for ci, (name, conf) in enumerate(cases.items()):
+        mod = SpecAugment(input_size=80, **conf)
+        mod.train()
+        torch.manual_seed(1000 + ci)
+        rec, orig, wrapped = _capture_randint()
+        torch.randint = wrapped
+        try:
+            y, _ = mod(feat.clone(), feat_len.clone())
+        finally:
+            torch.randint = orig
+        out[f"{name}_out"] = y
+        out[f"{name}_seed"] = np.int64(1000 + ci)
+        out[f"{name}_ndraw"] = np.int64(len(rec))
+        for j, r in enumerate(rec):
+            out[f"{name}_draw{j}"] = r
+    save("g2_specaug", **out)
+
+
+# ---- G3 posenc -----------------------------------------------------------------------------------
+
+def g3_posenc():
+    out = {}
+    for typ in ("mix", "sep"):
+        pe = PositionalEncoding(posenc_type=typ, d_model=64, max_len=300)
+        out[f"{typ}_rows"] = pe.posenc[0, [0, 1, 2, 17, 150, 299]]
+    g = torch.Generator().manual_seed(303)
+    x = torch.randn(2, 50, 64, generator=g)
+    pe = PositionalEncoding(d_model=64, emb_scale=True, emb_layernorm=True, posenc_scale=True, max_len=300)
+    sd = seeded_state(pe, 3)
+    pe.eval()
+    out.update(x=x, full_out=pe(x.clone()), **{"full_sd." + k: v for k, v in sd.items() if k != "posenc"})
+    pe2 = PositionalEncoding(d_model=64, max_len=300)
+    pe2.eval()
+    out.update(plain_out=pe2(x.clone()))
+    save("g3_posenc", **out)
+
+
+# ---- G4 layers: fwd + grads ----------------------------------------------------------------------
+
+def _grads(outputs, wrt):
+    loss = sum((o * torch.linspace(-1, 1, o.numel()).reshape(o.shape)).sum() for o in outputs)
+    return torch.autograd.grad(loss, wrt, allow_unused=True)
+
+
+def g4_layers():
+    out = {}
+    g = torch.Generator().manual_seed(404)
+    # MHA: d=64 h=4 (dh 16), both scale modes, padding mask and full (causal & padding) mask
+    for tag, by_head in (("mha_dmodel", False), ("mha_byhead", True)):
+        m = MultiHeadedAttention(num_heads=4, d_model=64, dropout=0.0, scale_dp_by_head=by_head)
+        sd = seeded_state(m, 41)
+        m.eval()
+        q = torch.randn(2, 9, 64, generator=g, requires_grad=True)
+        kv = torch.randn(2, 13, 64, generator=g, requires_grad=True)
+        mask = make_mask_from_len(torch.tensor([13, 8]))
+        y, p = m(kv, kv, q, mask)
+        gq, gkv, gw = _grads([y], [q, kv, m.q_layer.weight])
+        out.update({f"{tag}.q": q, f"{tag}.kv": kv, f"{tag}.mask": mask, f"{tag}.out": y, f"{tag}.probs": p,
+                    f"{tag}.gq": gq, f"{tag}.gkv": gkv, f"{tag}.gw_q": gw})
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+    # dh = 192 (FastSpeech2 shape: d=384, h=2), causal self-attention mask (B,T,T)
+    m = MultiHeadedAttention(num_heads=2, d_model=384, dropout=0.0)
+    sd = seeded_state(m, 42)
+    m.eval()
+    x = torch.randn(2, 11, 384, generator=g, requires_grad=True)
+    pad = make_mask_from_len(torch.tensor([11, 7]))
+    full = torch.logical_and(pad.repeat(1, 11, 1), TransformerDecoder.subsequent_mask(2, 11))
+    y, p = m(x, x, x, full)
+    (gx,) = _grads([y], [x])
+    out.update({"mha192.x": x, "mha192.mask": full, "mha192.out": y, "mha192.probs": p, "mha192.gx": gx})
+    out.update({f"mha192.sd.{k}": v for k, v in sd.items()})
+    # FFN linear (ReLU, GELU) and conv k=3 (ReLU)
+    for tag, conf in (("ffn_relu", dict()), ("ffn_gelu", dict(fdfwd_activation="GELU")),
+                      ("ffn_conv", dict(fdfwd_type="conv"))):
+        f = PositionwiseFeedForward(d_model=64, fdfwd_dim=160, dropout=0.0, **conf)
+        sd = seeded_state(f, 43)
+        f.eval()
+        x = torch.randn(2, 10, 64, generator=g, requires_grad=True)
+        y = f(x)
+        w_in = f.in_layer.weight if conf.get("fdfwd_type") != "conv" else f.in_layer.conv_lyr.weight
+        gx, gw = _grads([y], [x, w_in])
+        out.update({f"{tag}.x": x, f"{tag}.out": y, f"{tag}.gx": gx, f"{tag}.gw_in": gw})
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+    # encoder layer (pre-LN and post-LN) with grads wrt input and LN weight
+    for tag, first in (("enc_pre", True), ("enc_post", False)):
+        e = TransformerEncoderLayer(d_model=64, num_heads=4, fdfwd_dim=128, att_dropout=0.0, fdfwd_dropout=0.0,
+                                    res_dropout=0.0, fdfwd_activation="GELU", layernorm_first=first)
+        sd = seeded_state(e, 44)
+        e.eval()
+        x = torch.randn(2, 12, 64, generator=g, requires_grad=True)
+        mask = make_mask_from_len(torch.tensor([12, 5]))
+        y, p = e(x, mask)
+        gx, gln, gb = _grads([y], [x, e.att_layernorm.weight, e.multihead_att.output_layer.bias])
+        out.update({f"{tag}.x": x, f"{tag}.mask": mask, f"{tag}.out": y, f"{tag}.probs": p, f"{tag}.gx": gx,
+                    f"{tag}.g_attln_w": gln, f"{tag}.g_outb": gb})
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+    # decoder layer
+    d = TransformerDecoderLayer(d_model=64, num_heads=4, fdfwd_dim=128, att_dropout=0.0, fdfwd_dropout=0.0,
+                                res_dropout=0.0, fdfwd_activation="GELU", scale_dp_by_head=True)
+    sd = seeded_state(d, 45)
+    d.eval()
+    tgt = torch.randn(2, 7, 64, generator=g, requires_grad=True)
+    src = torch.randn(2, 12, 64, generator=g, requires_grad=True)
+    tpad = make_mask_from_len(torch.tensor([7, 4]))
+    tmask = torch.logical_and(tpad.repeat(1, 7, 1), TransformerDecoder.subsequent_mask(2, 7))
+    smask = make_mask_from_len(torch.tensor([12, 9]))
+    y, sp, ep = d(tgt, src, tmask, smask)
+    gt, gs = _grads([y], [tgt, src])
+    out.update({"dec.tgt": tgt, "dec.src": src, "dec.tmask": tmask, "dec.smask": smask, "dec.out": y,
+                "dec.self_probs": sp, "dec.encdec_probs": ep, "dec.gtgt": gt, "dec.gsrc": gs})
+    out.update({f"dec.sd.{k}": v for k, v in sd.items()})
+    save("g4_layers", **out)
+
+
+# ---- G5 stacks -----------------------------------------------------------------------------------
+
+def g5_stacks():
+    out = {}
+    g = torch.Generator().manual_seed(505)
+    enc = TransformerEncoder(d_model=64, num_heads=4, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                             fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", posenc_maxlen=200)
+    sd = seeded_state(enc, 51)
+    enc.eval()
+    x = torch.randn(2, 20, 64, generator=g)
+    mask = make_mask_from_len(torch.tensor([20, 13]))
+    y, m2, att, hid = enc(x.clone(), mask)
+    out.update({"enc.x": x, "enc.mask": mask, "enc.out": y, "enc.att0": att[0], "enc.att1": att[1],
+                "enc.hid0": hid[0], "enc.hid1": hid[1]})
+    out.update({f"enc.sd.{k}": v for k, v in sd.items() if not k.endswith("posenc.posenc")})
+    # TTS-flavoured encoder: conv FFN, posenc alpha, emb LN, uni-directional
+    enc2 = TransformerEncoder(d_model=48, num_heads=2, num_layers=2, fdfwd_dim=96, fdfwd_type="conv", posenc_dropout=0.0,
+                              att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0, posenc_scale=True, emb_layernorm=True,
+                              scale_dp_by_head=True, uni_direction=True, layernorm_first=False, posenc_maxlen=200)
+    sd = seeded_state(enc2, 52)
+    enc2.eval()
+    x2 = torch.randn(2, 15, 48, generator=g)
+    mask2 = make_mask_from_len(torch.tensor([15, 9]))
+    y2, m22, att2, hid2 = enc2(x2.clone(), mask2)
+    out.update({"enc2.x": x2, "enc2.mask": mask2, "enc2.out": y2, "enc2.mask_out": m22, "enc2.att1": att2[1]})
+    out.update({f"enc2.sd.{k}": v for k, v in sd.items() if not k.endswith("posenc.posenc")})
+    dec = TransformerDecoder(d_model=64, num_heads=4, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                             fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", emb_scale=False,
+                             posenc_maxlen=200)
+    sd = seeded_state(dec, 53)
+    dec.eval()
+    tgt = torch.randn(2, 9, 64, generator=g)
+    tmask = make_mask_from_len(torch.tensor([9, 6]))
+    yd, sa, ea, hd = dec(tgt.clone(), y.detach(), tmask, mask)
+    out.update({"dec.tgt": tgt, "dec.tmask": tmask, "dec.out": yd, "dec.self_att1": sa[1], "dec.encdec_att1": ea[1],
+                "dec.hid0": hd[0]})
+    out.update({f"dec.sd.{k}": v for k, v in sd.items() if not k.endswith("posenc.posenc")})
+    save("g5_stacks", **out)
+
+
+# ---- G6 criteria ---------------------------------------------------------------------------------
+
+def g6_losses():
+    out = {}
+    g = torch.Generator().manual_seed(606)
+    V = 37
+    logits = (torch.randn(3, 8, V, generator=g) * 2).requires_grad_(True)
+    text = torch.randint(1, V - 2, (3, 9), generator=g)
+    text_len = torch.tensor([9, 6, 4])
+    for i, l in enumerate(text_len):
+        text[i, 0] = V - 1
+        text[i, l - 1] = V - 1
+        text[i, l:] = 0
+    out.update(ce_logits=logits, text=text, text_len=text_len)
+    for tag, conf in (("ce0", dict()), ("ce02", dict(label_smoothing=0.2)),
+                      ("ce02n", dict(label_smoothing=0.2, length_normalized=True))):
+        loss = CrossEntropy(**conf)(logits=logits, text=text, text_len=text_len)
+        (gl,) = torch.autograd.grad(loss, logits)
+        out.update({f"{tag}.loss": loss, f"{tag}.grad": gl})
+    ctc_logits = (torch.randn(3, 21, V, generator=g) * 2).requires_grad_(True)
+    enc_len = torch.tensor([21, 15, 3])  # last one is infeasible (3 frames < 2 labels w/ repeat?) -> may be inf
+    text2 = text.clone()
+    text2[1, 1:5] = torch.tensor([5, 5, 7, 7])  # repeated labels exercise the skip rule
+    loss = CTCLoss()(ctc_logits, enc_len, text2.clone(), text_len.clone())
+    (gl,) = torch.autograd.grad(loss, ctc_logits)
+    per_utt = torch.nn.functional.ctc_loss(
+        ctc_logits.transpose(0, 1).log_softmax(-1),
+        torch.cat([text2[i, 1: text_len[i] - 1] for i in range(3)]), enc_len, text_len - 2, blank=0, reduction="none",
+        zero_infinity=True)
+    out.update(ctc_logits=ctc_logits, enc_len=enc_len, ctc_text=text2, ctc_loss=loss, ctc_grad=gl, ctc_per_utt=per_utt)
+    save("g6_losses", **out)
+
+
+# ---- G7 harness ----------------------------------------------------------------------------------
+
+def g7_harness():
+    g = torch.Generator().manual_seed(707)
+    d, H, V = 64, 4, 53
+    enc = TransformerEncoder(d_model=d, num_heads=H, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                             fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", posenc_maxlen=200)
+    emb = EmbedPrenet(embedding_dim=d, vocab_size=V)
+    dec = TransformerDecoder(d_model=d, num_heads=H, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                             fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", emb_scale=False,
+                             posenc_maxlen=200)
+    post, ctc_layer = TokenPostnet(input_size=d, vocab_size=V), TokenPostnet(input_size=d, vocab_size=V)
+    P = {}
+    for name, mod, seed in (("encoder", enc, 71), ("embed_mod", emb, 72), ("decoder", dec, 73), ("postnet", post, 74),
+                            ("ctc_layer", ctc_layer, 75)):
+        sd = seeded_state(mod, seed)
+        mod.eval()
+        for k, v in sd.items():
+            P[f"{name}.{k}"] = v
+    P["embed.weight"] = P.pop("embed_mod.embed.weight")
+    feat = torch.randn(3, 30, d, generator=g)
+    feat_len = torch.tensor([30, 22, 17])
+    text = torch.randint(1, V - 2, (3, 8), generator=g)
+    text_len = torch.tensor([8, 6, 5])
+    for i, l in enumerate(text_len):
+        text[i, 0] = V - 1
+        text[i, l - 1] = V - 1
+        text[i, l:] = 0
+    # sequencing of model/ar_asr.py:386-388 (eos strip), encoder/asr.py:126-131, decoder/ar_asr.py:49-78, :453-458, :550
+    dtext, dlen = text.clone(), text_len - 1
+    for i in range(3):
+        dtext[i, text_len[i] - 1] = 0
+    dtext = dtext[:, :-1]
+    fmask = make_mask_from_len(feat_len)
+    e, fmask, _, _ = enc(feat.clone(), fmask)
+    tmask = make_mask_from_len(dlen)
+    dd, _, _, _ = dec(src=e, src_mask=fmask, tgt=emb(dtext), tgt_mask=tmask)
+    logits, ctc_logits = post(dd), ctc_layer(e)
+    ce = CrossEntropy(label_smoothing=0.2)(logits=logits, text=text, text_len=text_len)
+    ctc = CTCLoss()(ctc_logits, feat_len.clone(), text.clone(), text_len.clone())
+    loss = 0.7 * ce + 0.3 * ctc
+    gsel = torch.autograd.grad(loss, [enc.trfm_layers[0].multihead_att.q_layer.weight, emb.embed.weight,
+                                      dec.trfm_layers[1].encdec_att.k_layer.bias, ctc_layer.linear.weight])
+    out = dict(feat=feat, feat_len=feat_len, text=text, text_len=text_len, enc=e, logits=logits, ctc_logits=ctc_logits,
+               ce=ce, ctc=ctc, loss=loss, g_enc0_q=gsel[0], g_embed=gsel[1], g_dec1_encdec_kb=gsel[2], g_ctc_w=gsel[3])
+    out.update({f"sd.{k}": v for k, v in P.items() if not k.endswith("posenc.posenc")})
+    save("g7_harness", **out)
+
+
+if __name__ == "__main__":
+    g1_frontend()
+    g2_specaug()
+    g3_posenc()
+    g4_layers()
+    g5_stacks()
+    g6_losses()
+    g7_harness()

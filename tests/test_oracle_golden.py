@@ -1,0 +1,219 @@
+"""CPU: the oracle (oracle/cpu_ref.py) against the golden vectors produced by the imported reference."""
+import math
+
+import pytest
+import torch
+
+from conftest import sub
+from oracle import cpu_ref as R
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), float((a - b).abs().max())
+
+
+ASR = dict(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025, n_mels=80)
+TTS = dict(sr=22050, hop_length=256, win_length=1024, n_fft=1024, n_mels=80, fmin=0, fmax=8000, mag_spec=True,
+           return_energy=True, clamp=1e-5, log_base=None)
+ODD = dict(sr=16000, hop_length=128, win_length=400, n_fft=512, n_mels=40, mel_scale="htk", mel_norm=False, log_base=None)
+
+
+def test_frontend_asr(golden):
+    g = golden("g1_frontend")
+    feat, flen = R.speech2mel(g["wave"], g["wave_len"], **ASR)
+    assert torch.equal(flen, g["asr_len"])
+    close(feat, g["asr_logmel"], atol=2e-4)  # fft-order rounding, amplified by log10 near the floor
+    close(R.mel_matrix(400, 80), g["asr_melw"], atol=0, rtol=0)
+    # explicit framing/rfft definition agrees as well (independent of torch.stft)
+    feat2, _ = R.speech2mel(g["wave"], g["wave_len"], explicit=True, **ASR)
+    close(feat2, g["asr_logmel"], atol=2e-4)
+    lin, _ = R.speech2linear(g["wave"], g["wave_len"], sr=16000, preemph=0.97, hop_length=0.010, win_length=0.025)
+    close(lin[:2, :40], g["asr_power"], atol=1e-6, rtol=1e-4)
+
+
+def test_frontend_tts_and_odd(golden):
+    g = golden("g1_frontend")
+    feat, flen, en, _ = R.speech2mel(g["wave"][:3], g["wave_len"][:3], **TTS)
+    assert torch.equal(flen, g["tts_len"])
+    close(feat, g["tts_logmel"], atol=2e-4)
+    close(en, g["tts_energy"], atol=1e-5, rtol=1e-4)
+    feat, flen = R.speech2mel(g["wave"][:2], g["wave_len"][:2], **ODD)
+    assert torch.equal(flen, g["odd_len"])
+    close(feat, g["odd_logmel"], atol=2e-4)
+    close(R.mel_matrix(512, 40, mel_scale="htk", mel_norm=False), g["odd_melw"], atol=0, rtol=0)
+
+
+def test_wave_len_not_mutated(golden):
+    g = golden("g1_frontend")
+    wl = g["wave_len"].clone()
+    R.speech2mel(g["wave"], wl, **ASR)
+    assert torch.equal(wl, g["wave_len"])
+
+
+SPECAUG_CASES = dict(
+    recipe=dict(freq_mask_width=15, freq_mask_num=4, time_mask_width=0.05, time_mask_num=5),
+    default=dict(),
+    nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
+    warponly=dict(freq_mask=False, time_mask=False),
+)
+
+
+@pytest.mark.parametrize("name", list(SPECAUG_CASES))
+def test_specaug_draws_bit_exact_and_output(golden, name):
+    g = golden("g2_specaug")
+    conf = dict(SPECAUG_CASES[name])
+    feat_norm = conf.pop("feat_norm", True)
+    torch.manual_seed(int(g[f"{name}_seed"]))
+    d = R.specaug_draw(g["feat_len"], 3, 80, **conf)
+    drawn = [x for x in (d["warp_center"], d["warp_pos"], d["freq_len"], d["freq_pos"], d["time_len"], d["time_pos"])
+             if x is not None]
+    assert len(drawn) == int(g[f"{name}_ndraw"])
+    for j, x in enumerate(drawn):
+        ref = g[f"{name}_draw{j}"]
+        assert torch.equal(torch.as_tensor(x).reshape(ref.shape), ref), (name, j)
+    for explicit in (False, True):
+        out = R.specaug_apply(g["feat"], g["feat_len"], d, feat_norm=feat_norm, explicit_warp=explicit)
+        close(out, g[f"{name}_out"], atol=1e-4 if explicit else 1e-6)
+
+
+def test_posenc(golden):
+    g = golden("g3_posenc")
+    rows = [0, 1, 2, 17, 150, 299]
+    for typ in ("mix", "sep"):
+        close(R.posenc_table(300, 64, typ)[0, rows], g[f"{typ}_rows"], atol=0, rtol=0)
+    P = {"p." + k: v for k, v in sub(g, "full_sd.").items()}
+    P["p.posenc"] = R.posenc_table(300, 64)
+    close(R.posenc_forward(g["x"], P, "p.", 64, emb_scale=True), g["full_out"], atol=1e-5)
+    close(R.posenc_forward(g["x"], {"p.posenc": P["p.posenc"]}, "p.", 64), g["plain_out"], atol=1e-6)
+
+
+def _weights(x):
+    return torch.linspace(-1, 1, x.numel()).reshape(x.shape)
+
+
+def test_mha_fwd_bwd(golden):
+    g = golden("g4_layers")
+    for tag, by_head in (("mha_dmodel", False), ("mha_byhead", True)):
+        q, kv = g[f"{tag}.q"].requires_grad_(), g[f"{tag}.kv"].requires_grad_()
+        P = {k: v.clone().requires_grad_() for k, v in sub(g, f"{tag}.sd.").items()}
+        y, p = R.mha(kv, kv, q, g[f"{tag}.mask"], P, "", 4, by_head)
+        close(y, g[f"{tag}.out"], atol=1e-5)
+        close(p, g[f"{tag}.probs"], atol=1e-6)
+        gq, gkv, gw = torch.autograd.grad((y * _weights(y)).sum(), [q, kv, P["q_layer.weight"]])
+        close(gq, g[f"{tag}.gq"], atol=1e-4)
+        close(gkv, g[f"{tag}.gkv"], atol=1e-4)
+        close(gw, g[f"{tag}.gw_q"], atol=1e-3, rtol=1e-4)
+    x = g["mha192.x"]
+    y, p = R.mha(x, x, x, g["mha192.mask"], sub(g, "mha192.sd."), "", 2)
+    close(y, g["mha192.out"], atol=1e-5)
+    close(p, g["mha192.probs"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,act,typ", [("ffn_relu", "ReLU", "linear"), ("ffn_gelu", "GELU", "linear"),
+                                         ("ffn_conv", "ReLU", "conv")])
+def test_ffn(golden, tag, act, typ):
+    g = golden("g4_layers")
+    x = g[f"{tag}.x"].requires_grad_()
+    P = {k: v.clone().requires_grad_() for k, v in sub(g, f"{tag}.sd.").items()}
+    y = R.ffn(x, P, "", act, typ)
+    close(y, g[f"{tag}.out"], atol=1e-5)
+    w = P["in_layer.weight"] if typ == "linear" else P["in_layer.conv_lyr.weight"]
+    gx, gw = torch.autograd.grad((y * _weights(y)).sum(), [x, w])
+    close(gx, g[f"{tag}.gx"], atol=1e-4)
+    close(gw, g[f"{tag}.gw_in"], atol=1e-3, rtol=1e-4)
+
+
+def test_encoder_decoder_layers(golden):
+    g = golden("g4_layers")
+    for tag, first in (("enc_pre", True), ("enc_post", False)):
+        x = g[f"{tag}.x"].requires_grad_()
+        P = {k: v.clone().requires_grad_() for k, v in sub(g, f"{tag}.sd.").items()}
+        y, p = R.encoder_layer(x, g[f"{tag}.mask"], P, "", 4, activation="GELU", layernorm_first=first)
+        close(y, g[f"{tag}.out"], atol=2e-5)
+        close(p, g[f"{tag}.probs"], atol=1e-6)
+        gx, gln, gb = torch.autograd.grad((y * _weights(y)).sum(),
+                                          [x, P["att_layernorm.weight"], P["multihead_att.output_layer.bias"]])
+        close(gx, g[f"{tag}.gx"], atol=2e-4)
+        close(gln, g[f"{tag}.g_attln_w"], atol=1e-3, rtol=1e-4)
+        close(gb, g[f"{tag}.g_outb"], atol=1e-3, rtol=1e-4)
+    tgt, src = g["dec.tgt"].requires_grad_(), g["dec.src"].requires_grad_()
+    y, sp, ep = R.decoder_layer(tgt, src, g["dec.tmask"], g["dec.smask"], sub(g, "dec.sd."), "", 4,
+                                scale_dp_by_head=True, activation="GELU")
+    close(y, g["dec.out"], atol=2e-5)
+    close(sp, g["dec.self_probs"], atol=1e-6)
+    close(ep, g["dec.encdec_probs"], atol=1e-6)
+    gt, gs = torch.autograd.grad((y * _weights(y)).sum(), [tgt, src])
+    close(gt, g["dec.gtgt"], atol=2e-4)
+    close(gs, g["dec.gsrc"], atol=2e-4)
+
+
+def test_stacks(golden):
+    g = golden("g5_stacks")
+    P = sub(g, "enc.sd.")
+    P["posenc.posenc"] = R.posenc_table(200, 64)
+    y, m, att, hid = R.transformer_encoder(g["enc.x"], g["enc.mask"], P, "", num_layers=2, num_heads=4, d_model=64,
+                                           activation="GELU")
+    close(y, g["enc.out"], atol=5e-5)
+    close(att[0], g["enc.att0"], atol=1e-6)
+    close(att[1], g["enc.att1"], atol=1e-6)
+    close(hid[0], g["enc.hid0"], atol=5e-5)
+    close(hid[1], g["enc.hid1"], atol=5e-5)
+    P2 = sub(g, "enc2.sd.")
+    P2["posenc.posenc"] = R.posenc_table(200, 48)
+    y2, m2, att2, _ = R.transformer_encoder(g["enc2.x"], g["enc2.mask"], P2, "", num_layers=2, num_heads=2, d_model=48,
+                                            fdfwd_type="conv", scale_dp_by_head=True, uni_direction=True,
+                                            layernorm_first=False)
+    close(y2, g["enc2.out"], atol=5e-5)
+    assert torch.equal(m2, g["enc2.mask_out"])
+    close(att2[1], g["enc2.att1"], atol=1e-6)
+    Pd = sub(g, "dec.sd.")
+    Pd["posenc.posenc"] = R.posenc_table(200, 64)
+    yd, sa, ea, hd = R.transformer_decoder(g["dec.tgt"], g["enc.out"], g["dec.tmask"], g["enc.mask"], Pd, "",
+                                           num_layers=2, num_heads=4, d_model=64, emb_scale=False, activation="GELU")
+    close(yd, g["dec.out"], atol=5e-5)
+    close(sa[1], g["dec.self_att1"], atol=1e-6)
+    close(ea[1], g["dec.encdec_att1"], atol=1e-6)
+    close(hd[0], g["dec.hid0"], atol=5e-5)
+
+
+def test_losses(golden):
+    g = golden("g6_losses")
+    for tag, conf in (("ce0", dict()), ("ce02", dict(label_smoothing=0.2)),
+                      ("ce02n", dict(label_smoothing=0.2, length_normalized=True))):
+        lg = g["ce_logits"].clone().requires_grad_()
+        loss = R.cross_entropy(lg, g["text"], g["text_len"], **conf)
+        close(loss, g[f"{tag}.loss"], atol=1e-5)
+        close(torch.autograd.grad(loss, lg)[0], g[f"{tag}.grad"], atol=1e-6)
+    lg = g["ctc_logits"].clone().requires_grad_()
+    loss = R.ctc_loss(lg, g["enc_len"], g["ctc_text"], g["text_len"])
+    close(loss, g["ctc_loss"], atol=1e-5)
+    close(torch.autograd.grad(loss, lg)[0], g["ctc_grad"], atol=1e-6)
+    # independent alpha recursion pins the per-utterance values (infeasible alignment -> inf -> zeroed)
+    lp = g["ctc_logits"].double().log_softmax(-1)
+    for i in range(3):
+        tgt = g["ctc_text"][i, 1: int(g["text_len"][i]) - 1].tolist()
+        nll = R.ctc_nll_explicit(lp[i, : int(g["enc_len"][i])], tgt)
+        ref = float(g["ctc_per_utt"][i])
+        assert (math.isinf(nll) and ref == 0.0) or abs(nll - ref) < 1e-4 * max(1.0, abs(ref)), (i, nll, ref)
+
+
+def test_harness(golden):
+    g = golden("g7_harness")
+    P = sub(g, "sd.")
+    P["encoder.posenc.posenc"] = R.posenc_table(200, 64)
+    P["decoder.posenc.posenc"] = R.posenc_table(200, 64)
+    for k in ("encoder.trfm_layers.0.multihead_att.q_layer.weight", "embed.weight",
+              "decoder.trfm_layers.1.encdec_att.k_layer.bias", "ctc_layer.linear.weight"):
+        P[k] = P[k].clone().requires_grad_()
+    cfg = dict(enc_layers=2, dec_layers=2, num_heads=4, d_model=64, activation="GELU", label_smoothing=0.2, ctc_weight=0.3)
+    o = R.asr_forward_loss(g["feat"], g["feat_len"], g["text"], g["text_len"], P, cfg)
+    close(o["enc"], g["enc"], atol=5e-5)
+    close(o["logits"], g["logits"], atol=1e-4)
+    close(o["ctc_logits"], g["ctc_logits"], atol=1e-4)
+    for k in ("ce", "ctc", "loss"):
+        close(o[k], g[k], atol=1e-4)
+    gs = torch.autograd.grad(o["loss"], [P["encoder.trfm_layers.0.multihead_att.q_layer.weight"], P["embed.weight"],
+                                         P["decoder.trfm_layers.1.encdec_att.k_layer.bias"], P["ctc_layer.linear.weight"]])
+    for a, k in zip(gs, ("g_enc0_q", "g_embed", "g_dec1_encdec_kb", "g_ctc_w")):
+        close(a, g[k], atol=1e-4, rtol=1e-3)
