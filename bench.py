@@ -1,0 +1,180 @@
+"""bench.py -- throughput of the MI355X hot path on synthetic 10 s @ 16 kHz x 32 batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend]
+
+One process per GPU (N > 1: launched by torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE from the env).  A step is
+one pass of the hot path over one per-GPU batch of 32 synthetic utterances; inputs are resident in HBM before the
+timed region.  The path shards by utterance with no data-path collective (weak scaling).  Rank 0 prints ONE JSON
+line (see the repo prompt's contract) with two extra objects:
+  roofline     -- algorithmic bytes of the dominant kernel / its HIP-event-measured launch time vs the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (a torch-CPU port of the reference op sequence) timed on this host's cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+ASR_FRONTEND = dict(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025, n_mels=80)
+SPECAUG = dict(freq_mask_width=15, freq_mask_num=4, time_mask_width=0.05, time_mask_num=5)
+BATCH, SAMPLES = 32, 160000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="frontend", choices=["frontend"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def synth_batch(seed: int, device):
+    g = torch.Generator().manual_seed(seed)
+    wave = (torch.randn(BATCH, SAMPLES, 1, generator=g) * 0.1)
+    lens = torch.full((BATCH,), SAMPLES, dtype=torch.int64)
+    return wave.to(device), lens.to(device), lens
+
+
+class FrontendWorkload:
+    """BASELINE.json configs[1]: waveform -> log-mel (fused HIP kernel) -> SpecAugment (warp + masks)."""
+
+    name = "frontend+specaug 32x10s@16kHz (BASELINE configs[1])"
+    dtype = "f32"
+    # algorithmic HBM bytes of the dominant kernel (the fused frontend) per launch: read the waveform once, write the
+    # log-mel once: 32*160000*4 + 32*1001*80*4
+    alg_bytes = BATCH * SAMPLES * 4 + BATCH * 1001 * 80 * 4
+    dominant = "frontend_kernel"
+
+    def __init__(self, device, seed):
+        from speechain_amd.module.augment.specaug import SpecAugment
+        from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
+
+        self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
+        self.sa = SpecAugment(input_size=80, **SPECAUG).to(device)
+        self.sa.train()
+        self.wave, self.lens, self.lens_host = synth_batch(seed, device)
+        self.ev = []
+
+    def step(self, timed: bool):
+        from speechain_amd._lib import lib
+
+        # HIP events are recorded on the launch stream tightly around the dominant kernel's launch
+        lib.timing = {"sc_frontend_logmel_fwd": self.ev} if timed else None
+        feat, flen = self.fe(self.wave, self.lens)
+        lib.timing = None
+        out, _ = self.sa(feat, flen)
+        return out
+
+    def dominant_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.ev) / max(1, len(self.ev))
+
+
+def cpu_baseline(seconds: float):
+    """The oracle's frontend + SpecAugment on the host cores, same batch shape; bounded to ~`seconds` of work."""
+    from oracle import cpu_ref as R  # test infrastructure used as the timed CPU port
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wave, _, lens = synth_batch(0, "cpu")
+    wave = wave.squeeze(-1)
+
+    def one():
+        feat, flen = R.speech2mel(wave, lens, **ASR_FRONTEND)
+        d = R.specaug_draw(flen, BATCH, 80, **SPECAUG)
+        return R.specaug_apply(feat, flen, d)
+
+    one()
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(BATCH * n / dt, 2), unit="utterances/s", cores=cores, kind="port",
+                sample=f"{n} batches of 32x160000 samples (frontend+specaug, torch-CPU oracle, fp32, {cores} threads)")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    torch.manual_seed(1234 + rank)
+    wl = FrontendWorkload(device, seed=rank)
+    for _ in range(args.warmup):
+        wl.step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kms = wl.dominant_ms()
+        achieved = wl.alg_bytes / (kms * 1e-3) / 1e9
+        line = {
+            "metric": "utterances/sec (10 s@16 kHz, bsz32)",
+            "value": round(BATCH * args.steps * world / elapsed, 2),
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": wl.dtype,
+            "data": "synthetic",
+            "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": SAMPLES,
+                       "sharding": f"{world} independent per-GPU batches, no collective"},
+            "roofline": {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Batch-level SpecAugment: host-side index draws (bit-identical to the reference's) + one HIP pass.
+
+Drop-in for ``speechain.module.augment.specaug.SpecAugment`` (speechain/module/augment/specaug.py): same kwargs
+(:19-32) and ``forward(feat, feat_len) -> (feat, feat_len)`` (:73-206).  The random integers are drawn with the very
+same ``torch.randint`` calls in the very same order (warp centre and position on the default CPU generator,
+:98-108; mask lengths and positions on ``feat.device``, :145-158 and :178-191), so under one seed the indices are
+bit-identical to the reference's wherever it runs.  Warp + mask + fill are then one launch of ``sc_specaug_fwd``.
+
+Difference kept on purpose: the input ``feat`` is not modified (the reference writes the warped rows back into its
+argument, :123-124, before ``masked_fill`` makes the returned copy).
+"""
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from speechain_amd._lib import lib, ptr, require_gpu, stream
+from speechain_amd.module.abs import Module
+
+
+class SpecAugment(Module):
+    def module_init(self, time_warp: bool = True, time_warp_window: int = 5, time_warp_mode: str = "bicubic",
+                    freq_mask: bool = True, freq_mask_width: Union[int, List[int]] = 30, freq_mask_num: int = 2,
+                    time_mask: bool = True, time_mask_width: Union[int, float, List] = 0.05, time_mask_num: int = 2,
+                    time_mask_ratio: float = 1.0, feat_norm: bool = True):
+        assert time_warp or freq_mask or time_mask, "You must specify at least one type of augmentation in SpecAugment!"
+        if time_warp and time_warp_mode != "bicubic":
+            raise NotImplementedError("speechain_amd SpecAugment implements the 'bicubic' time warp every recipe uses.")
+        self.feat_dim = None
+        if self.input_size is not None:
+            self.feat_dim = self.input_size
+            self.output_size = self.input_size
+        self.time_warp, self.time_warp_window, self.time_warp_mode = time_warp, time_warp_window, time_warp_mode
+        self.freq_mask = freq_mask
+        if isinstance(freq_mask_width, int):
+            freq_mask_width = [0, freq_mask_width]
+        elif not isinstance(freq_mask_width, List):
+            raise ValueError
+        if self.feat_dim is not None:
+            assert freq_mask_width[1] < self.feat_dim, (
+                "The number of maximum frequency masking bins cannot be larger than the feature dimension! "
+                f"freq_mask_width[1]={freq_mask_width[1]} and self.feat_dim={self.feat_dim}.")
+        self.freq_mask_width, self.freq_mask_num = freq_mask_width, freq_mask_num
+        self.time_mask = time_mask
+        if isinstance(time_mask_width, (int, float)):
+            time_mask_width = [0, time_mask_width]
+        elif not isinstance(time_mask_width, List):
+            raise ValueError
+        self.time_mask_width, self.time_mask_num = time_mask_width, time_mask_num
+        self.feat_norm = feat_norm
+
+    def draw(self, feat_len: torch.Tensor, batch_size: int, feat_dim: int, device) -> Dict:
+        """The random integers of one call, drawn exactly as specaug.py:87-191 does (host logic, no kernel)."""
+        tmax, tmin = int(feat_len.max().item()), int(feat_len.min().item())
+        d = dict(time_maxlen=tmax, time_minlen=tmin, warp_center=None, warp_pos=None, freq_len=None, freq_pos=None,
+                 time_len=None, time_pos=None)
+        W = self.time_warp_window
+        if self.time_warp and tmin > 2 * W + 1:
+            d["warp_center"] = torch.randint(low=W + 1, high=tmin - W, size=(1,))[0].item()
+            d["warp_pos"] = torch.randint(low=d["warp_center"] - W, high=d["warp_center"] + W, size=(1,))[0].item()
+        if self.freq_mask:
+            if self.feat_dim is None:
+                assert self.freq_mask_width[1] < feat_dim, (
+                    "The number of maximum frequency masking bins cannot be larger than the feature dimension! "
+                    f"self.freq_mask_width[1]={self.freq_mask_width[1]} and feat_dim={feat_dim}.")
+            d["freq_len"] = torch.randint(self.freq_mask_width[0], self.freq_mask_width[1] + 1,
+                                          size=(batch_size, self.freq_mask_num), device=device)
+            d["freq_pos"] = torch.randint(0, max(1, feat_dim - d["freq_len"].max().item()),
+                                          size=(batch_size, self.freq_mask_num), device=device)
+        if self.time_mask:
+            lo, hi = self.time_mask_width
+            if isinstance(lo, float):
+                lo = int(lo * tmin)
+            if isinstance(hi, float):
+                hi = int(hi * tmin)
+            hi = min(hi, tmin)
+            d["time_len"] = torch.randint(lo, hi + 1, size=(batch_size, self.time_mask_num), device=device)
+            d["time_pos"] = torch.randint(0, max(1, tmin - d["time_len"].max().item()),
+                                          size=(batch_size, self.time_mask_num), device=device)
+        return d
+
+    def apply(self, feat: torch.Tensor, draws: Dict) -> torch.Tensor:
+        """Warp + mask + fill on the device for given indices (``draws`` as returned by :meth:`draw`)."""
+        require_gpu(feat, "SpecAugment")
+        x = feat.float().contiguous()
+        B, T, Fd = x.shape
+        dev = x.device
+        i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
+        fl, fp, tl, tp = i64(draws["freq_len"]), i64(draws["freq_pos"]), i64(draws["time_len"]), i64(draws["time_pos"])
+        nf = 0 if fl is None else fl.size(1)
+        nt = 0 if tl is None else tl.size(1)
+        c = -1 if draws["warp_center"] is None else int(draws["warp_center"])
+        p = -1 if draws["warp_pos"] is None else int(draws["warp_pos"])
+        out = torch.empty_like(x)
+        tmin = int(draws["time_minlen"])
+        masked = nf > 0 or nt > 0
+        if masked and not self.feat_norm:
+            # fill value = mean of the (warped) features (specaug.py:203): warp first, reduce, then mask in place
+            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, None, None, 0, None, None, 0, None, stream())
+            fill = out.mean().reshape(1)
+            lib.call("sc_specaug_fwd", ptr(out), ptr(out), B, T, Fd, tmin, -1, -1, ptr(fl), ptr(fp), nf, ptr(tl), ptr(tp),
+                     nt, ptr(fill), stream())
+        else:
+            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, ptr(fl), ptr(fp), nf, ptr(tl), ptr(tp), nt,
+                     None, stream())
+        return out
+
+    def forward(self, feat: torch.Tensor, feat_len: torch.Tensor):
+        require_gpu(feat, "SpecAugment")
+        draws = self.draw(feat_len, feat.size(0), feat.size(-1), feat.device)
+        return self.apply(feat, draws), feat_len
+
+    def extra_repr(self) -> str:
+        out = ""
+        if self.time_warp:
+            out += f"time_warp_window={self.time_warp_window}, time_warp_mode={self.time_warp_mode}, "
+        if self.freq_mask:
+            out += f"\nfreq_mask_width={self.freq_mask_width}, freq_mask_num={self.freq_mask_num}, "
+        if self.time_mask:
+            out += f"\ntime_mask_width={self.time_mask_width}, time_mask_num={self.time_mask_num}"
+        return out

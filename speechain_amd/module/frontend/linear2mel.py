@@ -1,0 +1,59 @@
+"""Linear spectrogram -> (log-)mel spectrogram.
+
+Drop-in for ``speechain.module.frontend.linear2mel.LinearSpec2MelSpec`` (speechain/module/frontend/linear2mel.py):
+same kwargs (:20-33), the filterbank kept as the buffer ``mel_fbanks.weight`` (n_mels, n_fft//2+1) (:146-155),
+``forward(feat, feat_len)`` = filterbank, clamp, log / ln(base) (:163-189).
+"""
+import math
+
+import torch
+
+from speechain_amd._lib import lib, ptr, require_gpu, stream
+from speechain_amd.module.abs import Module
+from speechain_amd.module.frontend.melscale import mel_bands, mel_filterbank
+from speechain_amd.module.frontend.speech2linear import _BufferOnly
+
+
+class LinearSpec2MelSpec(Module):
+    def module_init(self, n_fft: int, n_mels: int, sr: int = 16000, fmin: float = 0.0, fmax: float = None,
+                    clamp: float = 1e-10, logging: bool = True, log_base: float = 10.0, mel_scale: str = "slaney",
+                    mel_norm: bool = True, mag_spec: bool = False):
+        self.sr = sr
+        self.stft_dim = n_fft // 2 + 1
+        self.n_mels = n_mels
+        self.fmin = fmin
+        self.fmax = fmax if fmax is not None else sr // 2
+        assert self.fmax > self.fmin, f"fmax must be larger than fmin, but got fmax={self.fmax} and fmin={self.fmin}!"
+        assert mel_scale in ["htk", "slaney"], f"mel_scale must be either 'htk' or 'slaney', but got mel_scale={mel_scale}"
+        self.mel_scale, self.mel_norm = mel_scale, mel_norm
+        self.output_size = n_mels
+        self.mel_fbanks = _BufferOnly(mel_filterbank(self.stft_dim, n_mels, sr, self.fmin, self.fmax, mel_scale, mel_norm))
+        self.clamp, self.logging, self.log_base, self.mag_spec = clamp, logging, log_base, mag_spec
+        self._bands = None
+
+    def bands(self):
+        """(lo, hi) int32 device tensors of each filter's support; recomputed when the buffer is replaced or moved."""
+        w = self.mel_fbanks.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._bands is None or self._bands[0] != key:
+            lo, hi = mel_bands(w)
+            self._bands = (key, lo.contiguous(), hi.contiguous())
+        return self._bands[1], self._bands[2]
+
+    def forward(self, feat: torch.Tensor, feat_len: torch.Tensor):
+        require_gpu(feat, "LinearSpec2MelSpec")
+        x = feat.float().contiguous()
+        out = torch.empty(*x.shape[:-1], self.n_mels, dtype=torch.float32, device=x.device)
+        lo, hi = self.bands()
+        lib.call("sc_mel_log_fwd", ptr(x), x.numel() // x.size(-1), x.size(-1), ptr(self.mel_fbanks.weight), ptr(lo), ptr(hi),
+                 self.n_mels, float(self.clamp), 1 if self.logging else 0,
+                 1.0 if self.log_base is None else math.log(self.log_base), ptr(out), stream())
+        return out, feat_len
+
+    def recover(self, feat: torch.Tensor, feat_len: torch.Tensor):
+        raise NotImplementedError("least-squares mel inversion (linear2mel.py:191-224) is outside the accelerated hot "
+                                  "path (SURVEY.md section 8f, row f4).")
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(\nstft_dim={self.stft_dim}, n_mels={self.n_mels}, fmin={self.fmin}, "
+                f"fmax={self.fmax}, mel_scale={self.mel_scale}, mel_norm={self.mel_norm}\n)")

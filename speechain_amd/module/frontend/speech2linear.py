@@ -1,0 +1,158 @@
+"""Waveform -> linear (power / magnitude) spectrogram on the MI355X.
+
+Drop-in for ``speechain.module.frontend.speech2linear.Speech2LinearSpec`` (reference file
+speechain/module/frontend/speech2linear.py): same constructor kwargs (:20-37), same buffer
+``preemph_filter.weight`` (1,1,2) (:103-116), same ``forward(speech, speech_len)`` returns (:142-250).
+All arithmetic is one launch of ``sc_frontend_logmel_fwd`` (csrc/frontend.hip).
+
+Differences kept on purpose: ``speech_len`` is NOT mutated in place (the reference adds the centre padding to the
+caller's tensor, :202); the output does not carry autograd history (the frontend has no trainable parameter).
+"""
+import math
+
+import torch
+
+from speechain_amd._lib import lib, ptr, require_gpu, stream
+from speechain_amd.module.abs import Module
+
+
+class _BufferOnly(torch.nn.Module):
+    """Holds one non-trainable tensor under the name ``weight`` (state_dict key ``<name>.weight``)."""
+
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.register_buffer("weight", weight)
+
+
+def _to_samples(value, sr: int) -> int:
+    return int(value * sr) if isinstance(value, float) else value
+
+
+class StftPlan:
+    """Device-resident windowed-DFT basis for (window, win_length, n_fft); built lazily per device."""
+
+    def __init__(self, window: str, win_length: int, n_fft: int):
+        self.window, self.win_length, self.n_fft = window, win_length, n_fft
+        self._basis = {}
+
+    def basis(self, device: torch.device) -> torch.Tensor:
+        key = (device.type, device.index)
+        if key not in self._basis:
+            win = getattr(torch, f"{self.window}_window")(self.win_length, dtype=torch.float32, device=device)
+            basis = torch.empty(lib.value("sc_frontend_basis_floats", self.n_fft), dtype=torch.float32, device=device)
+            lib.call("sc_frontend_basis_init", ptr(win), self.win_length, self.n_fft, ptr(basis), stream())
+            self._basis[key] = basis
+        return self._basis[key]
+
+
+def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPlan, hop: int, center: bool,
+                 preemphasis, mag_spec: bool, want_linear: bool, lin_clamp: float = 1e-10, lin_logging: bool = False,
+                 lin_log_base=None, want_energy: bool = False, melw: torch.Tensor = None, bands=None,
+                 clamp: float = 1e-10, logging: bool = True, log_base=10.0):
+    """Shared launcher of the fused frontend kernel.  Returns (mel|None, linear|None, energy|None, feat_len)."""
+    if speech.dim() == 3:
+        if speech.size(-1) != 1:
+            raise RuntimeError(
+                "Currently, we don't support multi-channel speech waveforms. If the speech is given in 3D vectors, "
+                f"the last dimension must be 1. But got speech.shape={tuple(speech.shape)}.")
+        speech = speech.squeeze(-1)
+    if speech.dim() != 2:
+        raise RuntimeError(f"speech must be (batch, samples[, 1]) but got shape {tuple(speech.shape)}")
+    require_gpu(speech, "the acoustic frontend")
+    wave = speech if (speech.dtype == torch.float32 and speech.stride(1) == 1) else speech.float().contiguous()
+    B, T_w = wave.shape
+    dev = wave.device
+    wave_len = speech_len.to(device=dev, dtype=torch.int64)
+    n_fft = plan.n_fft
+    pad = n_fft // 2 if center else 0
+    if T_w + 2 * pad < n_fft or (center and pad >= T_w):
+        raise RuntimeError(f"waveforms of {T_w} samples are too short for n_fft={n_fft}")
+    T = (T_w + 2 * pad - n_fft) // hop + 1
+    n_bins = n_fft // 2 + 1
+    mel = lin = energy = None
+    n_mels = 0
+    lo = hi = None
+    if melw is not None:
+        n_mels = melw.size(0)
+        mel = torch.empty(B, T, n_mels, dtype=torch.float32, device=dev)
+        lo, hi = bands
+    if want_linear:
+        lin = torch.empty(B, T, n_bins, dtype=torch.float32, device=dev)
+    if want_energy:
+        energy = torch.empty(B, T, dtype=torch.float32, device=dev)
+    feat_len = torch.empty(B, dtype=torch.int64, device=dev)
+    lib.call("sc_frontend_logmel_fwd", ptr(wave), ptr(wave_len), B, T_w, wave.stride(0),
+             1 if preemphasis is not None else 0, float(preemphasis or 0.0), n_fft, hop, 1 if center else 0,
+             ptr(plan.basis(dev)), ptr(melw), ptr(lo), ptr(hi), n_mels, 1 if mag_spec else 0, float(clamp),
+             1 if logging else 0, 1.0 if log_base is None else math.log(log_base), ptr(mel), ptr(energy), ptr(lin),
+             float(lin_clamp), 1 if lin_logging else 0, 1.0 if lin_log_base is None else math.log(lin_log_base),
+             ptr(feat_len), T, stream())
+    return mel, lin, energy, feat_len
+
+
+class Speech2LinearSpec(Module):
+    def module_init(self, hop_length, win_length, sr: int = 16000, n_fft: int = None, preemphasis: float = None,
+                    pre_stft_norm: str = None, window: str = "hann", center: bool = True, normalized: bool = False,
+                    onesided: bool = True, mag_spec: bool = False, return_energy: bool = False, clamp: float = 1e-10,
+                    logging: bool = False, log_base: float = None):
+        hop_length, win_length = _to_samples(hop_length, sr), _to_samples(win_length, sr)
+        if n_fft is None:
+            n_fft = win_length
+        if not onesided or normalized:
+            raise NotImplementedError("speechain_amd frontend implements the onesided, un-normalised STFT every "
+                                      "SpeeChain recipe uses (onesided=True, normalized=False).")
+        if pre_stft_norm not in (None, "min_max"):
+            # 'mean_std' only broadcasts for batch size 1 in the reference (speech2linear.py:179); not carried over
+            raise ValueError(f"pre_stft_norm must be None or 'min_max', got {pre_stft_norm}")
+        self.output_size = n_fft // 2 + 1
+        self.win_length, self.hop_length, self.n_fft, self.sr = win_length, hop_length, n_fft, sr
+        self.preemphasis = preemphasis
+        if preemphasis is not None:
+            self.preemph_filter = _BufferOnly(torch.tensor([-preemphasis, 1.0]).reshape(1, 1, 2))
+        self.pre_stft_norm = pre_stft_norm
+        self.stft_config = dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center,
+                                normalized=normalized, onesided=onesided, return_complex=True)
+        self.mag_spec, self.return_energy = mag_spec, return_energy
+        self.clamp, self.logging, self.log_base = clamp, logging, log_base
+        self._plan = StftPlan(window, win_length, n_fft)
+
+    def _prepare(self, speech: torch.Tensor, speech_len: torch.Tensor):
+        """Optional min-max pre-normalisation needs the pre-emphasised signal first (speech2linear.py:167-185);
+        that rare path runs un-fused.  Returns (speech, preemphasis coefficient still to be applied)."""
+        if self.pre_stft_norm is None:
+            return speech, self.preemphasis
+        require_gpu(speech, "the acoustic frontend")
+        x = speech.squeeze(-1) if speech.dim() == 3 else speech
+        if self.preemphasis is not None:
+            prev = torch.nn.functional.pad(x, (1, 0))[:, :-1]
+            x = x - self.preemphasis * prev
+            idx = torch.arange(x.size(1), device=x.device)[None, :]
+            x = x.masked_fill(idx >= speech_len.to(x.device).reshape(-1, 1), 0.0)
+        lo, hi = x.min(dim=1, keepdim=True)[0], x.max(dim=1, keepdim=True)[0]
+        return (x - lo) / (hi - lo) * 2 - 1, None
+
+    def forward(self, speech: torch.Tensor, speech_len: torch.Tensor):
+        speech, preemph = self._prepare(speech, speech_len)
+        _, lin, energy, feat_len = run_frontend(
+            speech, speech_len, plan=self._plan, hop=self.hop_length, center=self.stft_config["center"],
+            preemphasis=preemph, mag_spec=self.mag_spec, want_linear=True, lin_clamp=self.clamp,
+            lin_logging=self.logging, lin_log_base=self.log_base, want_energy=self.return_energy)
+        if self.return_energy:
+            return lin, feat_len, energy, feat_len
+        return lin, feat_len
+
+    def recover(self, feat: torch.Tensor, feat_len: torch.Tensor, inv_preemph_winlen: int = 100):
+        raise NotImplementedError("Griffin-Lim waveform recovery (speech2linear.py:252-351) is outside the accelerated "
+                                  "hot path (SURVEY.md section 8f, row f4).")
+
+    def get_sample_rate(self):
+        return self.sr
+
+    def __repr__(self) -> str:
+        s = (f"{self.__class__.__name__}(\nwin_length={self.win_length}, hop_length={self.hop_length}, "
+             f"n_fft={self.n_fft}, mag_spec={self.mag_spec}, ")
+        if self.preemphasis is not None:
+            s += f"preemphasis={self.preemphasis}, "
+        if self.pre_stft_norm is not None:
+            s += f"pre_stft_norm={self.pre_stft_norm}, "
+        return s + "\n)"

@@ -1,0 +1,185 @@
+"""GPU parity: fused HIP frontend + SpecAugment (through the C ABI) vs golden fixtures and the CPU oracle."""
+import pytest
+import torch
+
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+
+ASR = dict(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025, n_mels=80)
+TTS = dict(sr=22050, hop_length=256, win_length=1024, n_fft=1024, n_mels=80, fmin=0, fmax=8000, mag_spec=True,
+           return_energy=True, clamp=1e-5, log_base=None)
+ODD = dict(sr=16000, hop_length=128, win_length=400, n_fft=512, n_mels=40, mel_scale="htk", mel_norm=False, log_base=None)
+LOGMEL_TOL = 1e-3  # north-star bound on log-mel max-abs error; observed values are printed
+
+
+def _mod(conf, melw=None):
+    from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
+
+    m = Speech2MelSpec(**conf)
+    if melw is not None:
+        m.linear2mel.mel_fbanks.weight.copy_(melw)
+    return m.cuda()
+
+
+def _err(a, b):
+    return float((a.cpu() - b).abs().max())
+
+
+@pytest.mark.parametrize("tag,conf,n", [("asr", ASR, 4), ("tts", TTS, 3), ("odd", ODD, 2)])
+def test_golden_logmel(golden, tag, conf, n):
+    g = golden("g1_frontend")
+    m = _mod(conf, g[f"{tag}_melw"])
+    wl = g["wave_len"][:n].clone()
+    out = m(g["wave"][:n].cuda(), wl.cuda())
+    assert torch.equal(wl, g["wave_len"][:n])
+    assert torch.equal(out[1].cpu(), g[f"{tag}_len"])
+    e = _err(out[0], g[f"{tag}_logmel"])
+    print(f"{tag} log-mel max-abs err {e:.3e}")
+    assert e < LOGMEL_TOL
+    if tag == "tts":
+        ee = _err(out[2], g["tts_energy"])
+        print(f"tts energy max-abs err {ee:.3e}")
+        assert torch.allclose(out[2].cpu(), g["tts_energy"], atol=1e-4, rtol=1e-4)
+        assert torch.equal(out[3].cpu(), g["tts_len"])
+
+
+def test_golden_linear_power(golden):
+    from speechain_amd.module.frontend.speech2linear import Speech2LinearSpec
+
+    g = golden("g1_frontend")
+    m = Speech2LinearSpec(sr=16000, preemphasis=0.97, hop_length=0.010, win_length=0.025).cuda()
+    lin, flen = m(g["wave"].cuda(), g["wave_len"].cuda())
+    assert lin.shape == (4, 151, 201)
+    assert torch.allclose(lin[:2, :40].cpu(), g["asr_power"], atol=1e-6, rtol=2e-4)
+    full, _ = R.speech2linear(g["wave"], g["wave_len"], sr=16000, preemph=0.97, hop_length=0.010, win_length=0.025)
+    scale = float(full.abs().max())
+    assert _err(lin, full) < 2e-6 * scale
+    # frames beyond feat_len are exactly zero, as the reference leaves them
+    for i in range(4):
+        assert float(lin[i, int(flen[i]):].abs().max() if flen[i] < 151 else 0.0) == 0.0
+
+
+def test_default_filterbank_and_standalone_mel(golden):
+    from speechain_amd.module.frontend.linear2mel import LinearSpec2MelSpec
+
+    g = golden("g1_frontend")
+    m = _mod(ASR)  # own filterbank construction
+    feat, _ = m(g["wave"].cuda(), g["wave_len"].cuda())
+    assert _err(feat, g["asr_logmel"]) < LOGMEL_TOL
+    lin, _ = R.speech2linear(g["wave"], g["wave_len"], sr=16000, preemph=0.97, hop_length=0.010, win_length=0.025)
+    l2m = LinearSpec2MelSpec(n_fft=400, n_mels=80).cuda()
+    l2m.mel_fbanks.weight.copy_(g["asr_melw"])
+    out, _ = l2m(lin.cuda(), None)
+    assert _err(out, R.linear2mel(lin, g["asr_melw"])) < 1e-4
+
+
+@pytest.mark.parametrize("B,T_w,seed", [(1, 400, 0), (3, 4567, 1), (5, 16001, 2), (2, 200, 3)])
+def test_ragged_and_tiny_inputs_vs_oracle(B, T_w, seed):
+    gen = torch.Generator().manual_seed(seed)
+    wave = torch.randn(B, T_w, 1, generator=gen) * 0.1
+    lens = torch.randint(1, T_w + 1, (B,), generator=gen)
+    lens[0] = T_w
+    for i in range(B):
+        wave[i, lens[i]:] = 0
+    if T_w <= 200:  # reflect padding needs pad < T_w: the reference (torch.stft) errors too
+        with pytest.raises(RuntimeError):
+            _mod(ASR)(wave.cuda(), lens.cuda())
+        return
+    ref, rlen = R.speech2mel(wave, lens, **ASR)
+    out, olen = _mod(ASR)(wave.cuda(), lens.cuda())
+    assert torch.equal(olen.cpu(), rlen)
+    assert _err(out, ref) < LOGMEL_TOL
+
+
+def test_no_center_no_preemph_vs_oracle():
+    gen = torch.Generator().manual_seed(7)
+    wave = torch.randn(3, 5000, generator=gen)
+    lens = torch.tensor([5000, 4000, 777])
+    conf = dict(sr=16000, hop_length=100, win_length=320, n_fft=320, n_mels=23, center=False, fmin=20.0, fmax=7600.0)
+    ref, rlen = R.speech2mel(wave, lens, **conf)
+    out, olen = _mod(conf)(wave.cuda(), lens.cuda())
+    assert torch.equal(olen.cpu(), rlen)
+    assert _err(out, ref) < LOGMEL_TOL
+
+
+def test_full_size_batch_vs_oracle():
+    """BASELINE config 2: 32 x 10 s @ 16 kHz, N(0, 0.1^2), ragged lengths (seed 1)."""
+    gen = torch.Generator().manual_seed(1)
+    wave = torch.randn(32, 160000, 1, generator=gen) * 0.1
+    lens = torch.randint(80000, 160001, (32,), generator=gen)
+    lens[0] = 160000
+    ref, rlen = R.speech2mel(wave, lens, **ASR)
+    out, olen = _mod(ASR)(wave.cuda(), lens.cuda())
+    assert out.shape == (32, 1001, 80)
+    assert torch.equal(olen.cpu(), rlen)
+    e = _err(out, ref)
+    print(f"full-size log-mel max-abs err {e:.3e}")
+    assert e < LOGMEL_TOL
+    # size-independent property: padded frames hold exactly log10(clamp) = -10
+    for i in range(32):
+        if rlen[i] < 1001:
+            assert float((out[i, int(rlen[i]):] + 10.0).abs().max()) < 1e-5
+
+
+SPECAUG_CASES = dict(
+    recipe=dict(freq_mask_width=15, freq_mask_num=4, time_mask_width=0.05, time_mask_num=5),
+    default=dict(),
+    nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
+    warponly=dict(freq_mask=False, time_mask=False),
+)
+
+
+def _golden_draws(g, name, conf):
+    keys = []
+    if conf.get("time_warp", True):
+        keys += ["warp_center", "warp_pos"]
+    if conf.get("freq_mask", True):
+        keys += ["freq_len", "freq_pos"]
+    if conf.get("time_mask", True):
+        keys += ["time_len", "time_pos"]
+    d = dict(time_minlen=int(g["feat_len"].min()), time_maxlen=int(g["feat_len"].max()), warp_center=None, warp_pos=None,
+             freq_len=None, freq_pos=None, time_len=None, time_pos=None)
+    assert len(keys) == int(g[f"{name}_ndraw"])
+    for j, k in enumerate(keys):
+        v = g[f"{name}_draw{j}"]
+        d[k] = int(v.reshape(-1)[0]) if k.startswith("warp") else v
+    return d
+
+
+@pytest.mark.parametrize("name", list(SPECAUG_CASES))
+def test_specaug_golden(golden, name):
+    from speechain_amd.module.augment.specaug import SpecAugment
+
+    g = golden("g2_specaug")
+    conf = SPECAUG_CASES[name]
+    mod = SpecAugment(input_size=80, **conf)
+    d = _golden_draws(g, name, conf)
+    x = g["feat"].cuda()
+    out = mod.apply(x, d)
+    assert torch.equal(x.cpu(), g["feat"])  # input untouched
+    e = _err(out, g[f"{name}_out"])
+    print(f"specaug {name} max-abs err {e:.3e}")
+    assert e < 1e-4
+    # masked positions are bit-exact: the mask indices are integers
+    mask = R.specaug_mask(d, 3, 120, 80)
+    if mask is not None and conf.get("feat_norm", True):
+        assert float(out.cpu()[mask].abs().max()) == 0.0
+
+
+def test_specaug_forward_full_size_properties():
+    from speechain_amd.module.augment.specaug import SpecAugment
+
+    torch.manual_seed(11)
+    mod = SpecAugment(input_size=80, **SPECAUG_CASES["recipe"]).cuda()
+    feat = torch.randn(32, 1001, 80).cuda()
+    flen = torch.randint(600, 1002, (32,))
+    torch.manual_seed(5)
+    out, olen = mod(feat, flen)
+    torch.manual_seed(5)
+    d = R.specaug_draw(flen, 32, 80, device="cuda", **SPECAUG_CASES["recipe"])  # same generator stream, same integers
+    ref = R.specaug_apply(feat.cpu(), flen, d)
+    assert olen is flen
+    assert _err(out, ref) < 1e-4
+    assert torch.equal(out[:, int(flen.min()):].cpu()[~R.specaug_mask(d, 32, 1001, 80)[:, int(flen.min()):]],
+                       feat[:, int(flen.min()):].cpu()[~R.specaug_mask(d, 32, 1001, 80)[:, int(flen.min()):]])
