@@ -85,7 +85,8 @@ def cpu_baseline(seconds: float):
     """The oracle's frontend + SpecAugment on the host cores, same batch shape; bounded to ~`seconds` of work."""
     from oracle import cpu_ref as R  # test infrastructure used as the timed CPU port
 
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core share of the host; more torch threads than that only thrash
+    cores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", 16)))
     torch.set_num_threads(cores)
     wave, _, lens = synth_batch(0, "cpu")
     wave = wave.squeeze(-1)

@@ -73,6 +73,89 @@ int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, i
                    const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                    const long long* time_pos, int nt, const float* fill, hipStream_t stream);
 
+/* ---- transformer primitives -------------------------------------------------------------------------------
+ * `dtype` selects the activation type of a call: 0 = float32 (exact-f32 matrix cores, parity path),
+ * 1 = bfloat16 (bf16 matrix cores with f32 accumulation, training path).  Statistics, biases, gammas, losses and
+ * gradients of parameters are always float32. */
+
+/* C[z][m][n] = epilogue(alpha * sum_k opA[z][m][k] * opB[z][n][k]),  z = z1 * nb2 + z2 over nb1 x nb2 batches.
+ * opA is M x K: element (m,k) at A[m*lda + k] (ta = 0) or A[k*lda + m] (ta = 1); opB is N x K likewise (tb).
+ * Replaces nn.Linear / torch.matmul and their autograd products at speechain/module/transformer/attention.py:72-79,
+ * 99-106,131, feed_forward.py:93-101 and speechain/module/postnet/token.py:49.
+ * Epilogue, in order: v = alpha*acc + bias[n];  pre_out <- v (optional);
+ *   aux_mode 2: v *= act'(aux[m][n])  else  v = act(v)   (act: 0 none, 1 ReLU, 2 exact GELU);
+ *   dropout(drop_p) with the stateless generator keyed (seed, offset + linear index of (z,m,n));
+ *   aux_mode 1: v += aux[m][n];  store as `dtype`, or as float32 when out_f32 (optionally accumulating). */
+int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
+            long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2,
+            long long sC1, long long sC2, float alpha, const float* bias, int act, void* pre_out, const void* aux,
+            long long ldaux, int aux_mode, float drop_p, unsigned long long seed, unsigned long long offset, int out_f32,
+            int accumulate, hipStream_t stream);
+
+/* nn.LayerNorm over the last dim D of an (R, D) matrix (encoder.py:97-98,291-292; decoder.py:90-92; pos_enc.py:94-95);
+ * mean/rstd (R,) are saved for the backward pass (may be null).  Backward returns dx and the parameter gradients;
+ * `workspace` needs sc_layernorm_bwd_workspace(R, D) bytes. */
+int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                     long long R, int D, float eps, hipStream_t stream);
+long long sc_layernorm_bwd_workspace(long long R, int D);
+int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     void* dx, float* dgamma, float* dbeta, long long R, int D, void* workspace, long long ws_bytes,
+                     hipStream_t stream);
+
+/* out[n] = sum_r x[r][n] (bias gradients); deterministic two-stage reduction. */
+long long sc_colsum_workspace(long long R, int N);
+int sc_colsum(int dtype, const void* x, long long R, int N, long long ld, float* out, void* workspace, long long ws_bytes,
+              hipStream_t stream);
+
+/* Masked softmax over the last dim of (Z, Tq, ld) scores, Z = B*H (attention.py:88-95): positions where the bool
+ * mask (B, Tq|1, Tk; strides mask_b, mask_q; may be null) is false, or k > q when `causal`, get probability 0.
+ * P receives the probabilities (the reference's returned `score_soft`), Pd (optional) the dropped-out copy fed to
+ * P.V.  Columns [Tk, ld) are written as zeros.  Backward: dS = P * (dP - sum_k dP*P) * out_scale with
+ * dP = dPd * keepmask / (1 - p) regenerated from (seed, offset). */
+int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, int H, int Tq, int Tk, long long ld,
+                   const unsigned char* mask, long long mask_b, long long mask_q, int causal, float drop_p,
+                   unsigned long long seed, unsigned long long offset, hipStream_t stream);
+int sc_softmax_bwd(int dtype, const void* P, const void* dPd, void* dS, long long rows, int Tk, long long ld, float out_scale,
+                   float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
+
+/* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
+ * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
+ * lse[r] is kept for the backward pass, which writes dlogits = grow[r]/temperature * (softmax - (1-eps)*onehot - eps/V). */
+int sc_ce_fwd(int dtype, const void* logits, const long long* target, long long R, int V, long long ld, float temperature,
+              float smoothing, float* row_loss, float* lse, hipStream_t stream);
+int sc_ce_bwd(int dtype, const void* logits, const long long* target, const float* lse, const float* grow, long long R, int V,
+              long long ld, float temperature, float smoothing, void* dlogits, hipStream_t stream);
+
+/* lse[r] = logsumexp_v logits[r][v] */
+int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream);
+
+/* CTC negative log-likelihood per utterance and its gradient w.r.t. the logits (speechain/criterion/ctc.py:48-65 =
+ * log_softmax + F.ctc_loss(reduction='none')).  logits (B, Tmax, V); lse (B, Tmax) from sc_row_lse; tgt holds label
+ * ids with row stride tgt_stride; alpha is a (B, Tmax, Smax) float workspace, Smax >= 2*max(tgt_len)+1.
+ * nll may be +inf (infeasible alignment); the caller applies zero_infinity through gscale[b] (= upstream/B, or 0). */
+int sc_ctc_fwd(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+               long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, float* alpha,
+               float* nll, hipStream_t stream);
+int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+               long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, const float* alpha,
+               const float* nll, const float* gscale, void* grad, hipStream_t stream);
+
+/* dtype casts (0 = f32, 1 = bf16) and the transposed cast out[c][r] = in[r][c] of an (R, C) f32 matrix. */
+int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
+int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, long long ld_out, hipStream_t stream);
+
+/* y = dropout(x * xscale + table[t] * (*alpha)) for x (B, T, D), table (>= T, D) f32 (pos_enc.py:168-182). */
+int sc_posenc_fwd(int dtype, const void* x, const float* table, const float* alpha, float xscale, void* y, long long B, int T,
+                  int D, float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
+
+/* y = x * scale * keepmask / (1 - p) with the stateless generator (seed, offset + index). */
+int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, unsigned long long seed,
+               unsigned long long offset, hipStream_t stream);
+
+/* dpre = dy * act'(pre) * keepmask / (1 - p): backward of dropout(act(.)) when the upstream gradient is not a GEMM result. */
+int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
+               unsigned long long seed, unsigned long long offset, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

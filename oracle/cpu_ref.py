@@ -166,7 +166,7 @@ def speech2mel(wave: Tensor, wave_len: Tensor, *, n_mels: int, hop_length, win_l
                         explicit=explicit)
     if mel_w is None:
         mel_w = mel_matrix(n_fft, n_mels, sr, fmin, fmax, mel_scale, mel_norm)
-    feat = linear2mel(out[0], mel_w, clamp, logging, log_base)
+    feat = linear2mel(out[0], mel_w.to(out[0].dtype), clamp, logging, log_base)
     if return_energy:
         return feat, out[1], out[2], out[3]
     return feat, out[1]

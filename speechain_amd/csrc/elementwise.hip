@@ -1,0 +1,151 @@
+// Element-wise helpers of the transformer path for gfx950 (HBM-bound; 8 elements = 16/32 bytes per lane):
+//   dtype casts (f32 master weights -> bf16 compute copies, plain and transposed)
+//   positional-encoding add with scale / learnable alpha / dropout -- speechain/module/transformer/pos_enc.py:168-182
+//   dropout apply (forward of residual dropout's backward: dy * keep / (1 - p)) -- encoder.py:119,134; decoder.py:126,150,166
+#include "sc_common.h"
+
+namespace {
+
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33;
+  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+  static __device__ __forceinline__ float ld(const void* p, long long i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, long long i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct Io<unsigned short> {
+  static __device__ __forceinline__ float ld(const void* p, long long i) { return sc_bf16_to_f32(((const unsigned short*)p)[i]); }
+  static __device__ __forceinline__ void st(void* p, long long i, float v) { ((unsigned short*)p)[i] = sc_f32_to_bf16(v); }
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const void* in, void* out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) Io<TO>::st(out, i, Io<TI>::ld(in, i));
+}
+
+// out[c][r] = in[r][c] for an (R, C) f32 matrix -> (C, R) matrix of TO, via a 32 x 33 LDS tile
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* in, void* out, int R, int C, long long ld_out) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < C) ? in[(long long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < C && r < R) Io<TO>::st(out, (long long)c * ld_out + r, tile[tx][j]);
+  }
+}
+
+// y[b][t][d] = dropout(x[b][t][d] * xscale + table[t][d] * alpha)
+template <typename T>
+__global__ __launch_bounds__(256) void posenc_kernel(const void* x, const float* table, const float* alpha, float xscale, void* y,
+                                                     long long B, int Tn, int D, float drop_p, unsigned long long seed,
+                                                     unsigned long long offset) {
+  const long long n = B * Tn * D;
+  const long long td = (long long)Tn * D;
+  const float a = alpha ? *alpha : 1.f;
+  const float keep = 1.f / (1.f - drop_p);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v = Io<T>::ld(x, i) * xscale + table[i % td] * a;
+    if (drop_p > 0.f) v = (uniform01(seed, offset + i) < drop_p) ? 0.f : v * keep;
+    Io<T>::st(y, i, v);
+  }
+}
+
+// y = x * scale * keepmask / (1 - p)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const void* x, void* y, long long n, float scale, float drop_p,
+                                                      unsigned long long seed, unsigned long long offset) {
+  const float keep = scale / (1.f - drop_p);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v = Io<T>::ld(x, i);
+    v = (drop_p > 0.f && uniform01(seed, offset + i) < drop_p) ? 0.f : v * keep;
+    Io<T>::st(y, i, v);
+  }
+}
+
+// dpre = dy * act'(pre) * keepmask / (1 - p)     (act: 0 none, 1 ReLU, 2 exact GELU)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
+                                                      unsigned long long seed, unsigned long long offset) {
+  const float keep = 1.f / (1.f - drop_p);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    float g = Io<T>::ld(dy, i);
+    const float x = Io<T>::ld(pre, i);
+    if (act == 1) g = x > 0.f ? g : 0.f;
+    else if (act == 2) g *= 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+    if (drop_p > 0.f) g = (uniform01(seed, offset + i) < drop_p) ? 0.f : g * keep;
+    Io<T>::st(dpre, i, g);
+  }
+}
+
+inline unsigned grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// dtype codes: 0 = f32, 1 = bf16
+SC_API int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream) {
+  SC_CHECK_ARG(in && out && n >= 1, "sc_cast: bad arguments");
+  if (dtype_in == 0 && dtype_out == 1) hipLaunchKernelGGL((cast_kernel<float, unsigned short>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  else if (dtype_in == 1 && dtype_out == 0) hipLaunchKernelGGL((cast_kernel<unsigned short, float>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  else if (dtype_in == 0 && dtype_out == 0) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  else hipLaunchKernelGGL((cast_kernel<unsigned short, unsigned short>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
+  SC_LAUNCH_CHECK("cast_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, long long ld_out, hipStream_t stream) {
+  SC_CHECK_ARG(in && out && R >= 1 && C >= 1 && ld_out >= R, "sc_cast_transpose: bad arguments");
+  dim3 grid(sc_cdiv(C, 32), sc_cdiv(R, 32));
+  if (dtype_out == 1) hipLaunchKernelGGL(cast_transpose_kernel<unsigned short>, grid, dim3(256), 0, stream, in, out, R, C, ld_out);
+  else hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, stream, in, out, R, C, ld_out);
+  SC_LAUNCH_CHECK("cast_transpose_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_posenc_fwd(int dtype, const void* x, const float* table, const float* alpha, float xscale, void* y, long long B,
+                         int T, int D, float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(x && table && y && B >= 1 && T >= 1 && D >= 1, "sc_posenc_fwd: bad arguments");
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_posenc_fwd: dropout p=%f", drop_p);
+  const long long n = B * T * D;
+  if (dtype == 0) hipLaunchKernelGGL(posenc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, x, table, alpha, xscale, y, B, T, D, drop_p, seed, offset);
+  else hipLaunchKernelGGL(posenc_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, x, table, alpha, xscale, y, B, T, D, drop_p, seed, offset);
+  SC_LAUNCH_CHECK("posenc_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, unsigned long long seed,
+                      unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(x && y && n >= 1, "sc_dropout: bad arguments");
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_dropout: dropout p=%f", drop_p);
+  if (dtype == 0) hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, scale, drop_p, seed, offset);
+  else hipLaunchKernelGGL(dropout_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, scale, drop_p, seed, offset);
+  SC_LAUNCH_CHECK("dropout_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
+                      unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(dy && pre && dpre && n >= 1, "sc_act_bwd: bad arguments");
+  if (dtype == 0) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
+  else hipLaunchKernelGGL(act_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
+  SC_LAUNCH_CHECK("act_bwd_kernel");
+  return SC_OK;
+}

@@ -1,0 +1,510 @@
+// Batched matrix product with fused epilogue on the gfx950 matrix cores -- the workhorse behind every
+// nn.Linear / torch.matmul call site of the reference's transformer path (paths under /root/reference/):
+//   speechain/module/transformer/attention.py:72-79,99-106,131   (Q/K/V/out projections, QK^T, PV)
+//   speechain/module/transformer/feed_forward.py:93-101          (FFN in/out layers + activation + dropout)
+//   speechain/module/postnet/token.py:49                         (vocabulary heads)
+// and their autograd backward (dgrad / wgrad) products.
+//
+//   C[z][m][n] = epilogue( alpha * sum_k opA[z][m][k] * opB[z][n][k] )
+//
+// opA is M x K, opB is N x K ("NT" form: nn.Linear's y = x W^T with W stored (out, in)).  Either operand may be
+// stored with its ROW index contiguous instead of k (ta / tb = 1), which covers dgrad-free wgrad (dW = dy^T x),
+// P V and the attention backward products without materialising transposes in HBM.
+//
+// Two arithmetic modes, same tiling (128 x 128 output tile per 256-thread workgroup, 4 waves as 2 x 2, each wave
+// 64 x 64 = 2 x 2 MFMA 32x32 accumulators):
+//   bf16 in / f32 accumulate : v_mfma_f32_32x32x16_bf16, BK = 32   (training / bench path)
+//   f32  in / f32 accumulate : v_mfma_f32_32x32x2_f32,   BK = 16   (exact-f32 parity path; a k-ordered fmaf chain)
+// Global -> registers -> LDS staging with double-buffered LDS and one barrier per K tile; k-contiguous operands
+// are staged with 16-byte loads/stores into rows padded to 80 B (bf16) / 68 B (f32) so the MFMA fragment reads
+// are bank-conflict free; row-contiguous operands are transposed on their way into LDS.
+#include "sc_common.h"
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { AUX_NONE = 0, AUX_ADD = 1, AUX_ACT_GRAD = 2 };
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  int M, N, K;
+  long long lda, ldb, ldc;
+  int nb2;
+  long long sA1, sA2, sB1, sB2, sC1, sC2;
+  float alpha;
+  const float* bias;
+  int act;
+  void* pre_out;
+  const void* aux;
+  long long ldaux;
+  int aux_mode;
+  float drop_p;
+  unsigned long long seed, offset;
+  int out_f32;
+  int accumulate;
+  int a_vec, b_vec;  // 16-byte vector loads allowed for A / B
+  int c_vec, c_vec32;  // vector accesses allowed for C/aux/pre_out in the compute dtype / for an f32 C
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// counter-based hash RNG (murmur3 finaliser over seed ^ 64-bit counter): uniform in [0,1)
+__device__ __forceinline__ float sc_uniform(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33;
+  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float load(const void* p, long long i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store(void* p, long long i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct Elem<unsigned short> {
+  static __device__ __forceinline__ float load(const void* p, long long i) { return sc_bf16_to_f32(((const unsigned short*)p)[i]); }
+  static __device__ __forceinline__ void store(void* p, long long i, float v) { ((unsigned short*)p)[i] = sc_f32_to_bf16(v); }
+};
+
+constexpr int STG_LD = 68;  // f32 row stride of a wave's 32 x 64 staging tile (272 B: 16-byte aligned, bank-skewed)
+
+__device__ __forceinline__ float epilogue_elem(const GemmArgs& p, float v, float bias, float aux, bool has_aux,
+                                               unsigned long long idx) {
+  v = v * p.alpha + bias;
+  if (p.aux_mode == AUX_ACT_GRAD) {
+    if (p.act == ACT_RELU) v = aux > 0.f ? v : 0.f;
+    else if (p.act == ACT_GELU) v *= gelu_grad_f(aux);
+  } else {
+    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == ACT_GELU) v = gelu_f(v);
+  }
+  if (p.drop_p > 0.f) {
+    const float u = sc_uniform(p.seed, p.offset + idx);
+    v = (u < p.drop_p) ? 0.f : v * (1.f / (1.f - p.drop_p));
+  }
+  if (p.aux_mode == AUX_ADD) v += aux;
+  return v;
+}
+
+// Epilogue of one wave's 32 x 64 sub-tile held in its private LDS staging area: every lane owns runs of 8
+// consecutive columns, so bias/aux loads and the C store are 16-byte (bf16) / 32-byte (f32) vector accesses.
+template <typename T>
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const float* stage, long long zoffC, int z, int mbase,
+                                              int nbase, int lane) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  for (int it = 0; it < 4; ++it) {
+    const int q = lane + 64 * it;
+    const int row = q >> 3, cg = q & 7;
+    const int m = mbase + row, n = nbase + cg * 8;
+    if (m >= p.M || n >= p.N) continue;
+    const f32x4 s0 = *(const f32x4*)(stage + row * STG_LD + cg * 8);
+    const f32x4 s1 = *(const f32x4*)(stage + row * STG_LD + cg * 8 + 4);
+    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    const int nv = min(8, p.N - n);
+    const long long ci = zoffC + (long long)m * p.ldc + n;
+    const long long ai = zoffC + (long long)m * p.ldaux + n;
+    float aux[8];
+    const bool has_aux = p.aux_mode != AUX_NONE;
+    if (has_aux) {
+      if (nv == 8 && p.c_vec) {
+        if (kBf16) {
+          const uint4 u = *(const uint4*)((const unsigned short*)p.aux + ai);
+          const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { aux[2 * j] = __uint_as_float(w[j] << 16); aux[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+        } else {
+          const float4 a0 = *(const float4*)((const float*)p.aux + ai), a1 = *(const float4*)((const float*)p.aux + ai + 4);
+          aux[0] = a0.x; aux[1] = a0.y; aux[2] = a0.z; aux[3] = a0.w; aux[4] = a1.x; aux[5] = a1.y; aux[6] = a1.z; aux[7] = a1.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aux[j] = j < nv ? Elem<T>::load(p.aux, ai + j) : 0.f;
+      }
+    }
+    float pre[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float bias = (p.bias && j < nv) ? p.bias[n + j] : 0.f;
+      pre[j] = v[j] * p.alpha + bias;
+      const unsigned long long idx = ((unsigned long long)z * p.M + m) * p.N + n + j;
+      v[j] = epilogue_elem(p, v[j], bias, has_aux ? aux[j] : 0.f, has_aux, idx);
+    }
+    if (p.out_f32) {
+      float* c = (float*)p.C + ci;
+      if (nv == 8 && p.c_vec32) {
+        float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+        if (p.accumulate) {
+          const float4 c0 = *(const float4*)c, c1 = *(const float4*)(c + 4);
+          o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+        }
+        *(float4*)c = o0;
+        *(float4*)(c + 4) = o1;
+      } else {
+        for (int j = 0; j < nv; ++j) c[j] = p.accumulate ? c[j] + v[j] : v[j];
+      }
+    } else if (kBf16) {
+      unsigned short* c = (unsigned short*)p.C + ci;
+      unsigned short* pr = p.pre_out ? (unsigned short*)p.pre_out + ci : nullptr;
+      if (nv == 8 && p.c_vec) {
+        uint4 o;
+        o.x = sc_f32_to_bf16(v[0]) | ((unsigned)sc_f32_to_bf16(v[1]) << 16);
+        o.y = sc_f32_to_bf16(v[2]) | ((unsigned)sc_f32_to_bf16(v[3]) << 16);
+        o.z = sc_f32_to_bf16(v[4]) | ((unsigned)sc_f32_to_bf16(v[5]) << 16);
+        o.w = sc_f32_to_bf16(v[6]) | ((unsigned)sc_f32_to_bf16(v[7]) << 16);
+        *(uint4*)c = o;
+        if (pr) {
+          o.x = sc_f32_to_bf16(pre[0]) | ((unsigned)sc_f32_to_bf16(pre[1]) << 16);
+          o.y = sc_f32_to_bf16(pre[2]) | ((unsigned)sc_f32_to_bf16(pre[3]) << 16);
+          o.z = sc_f32_to_bf16(pre[4]) | ((unsigned)sc_f32_to_bf16(pre[5]) << 16);
+          o.w = sc_f32_to_bf16(pre[6]) | ((unsigned)sc_f32_to_bf16(pre[7]) << 16);
+          *(uint4*)pr = o;
+        }
+      } else {
+        for (int j = 0; j < nv; ++j) {
+          c[j] = sc_f32_to_bf16(v[j]);
+          if (pr) pr[j] = sc_f32_to_bf16(pre[j]);
+        }
+      }
+    } else {
+      float* c = (float*)p.C + ci;
+      float* pr = p.pre_out ? (float*)p.pre_out + ci : nullptr;
+      if (nv == 8 && p.c_vec) {
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (pr) {
+          *(float4*)pr = make_float4(pre[0], pre[1], pre[2], pre[3]);
+          *(float4*)(pr + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+        }
+      } else {
+        for (int j = 0; j < nv; ++j) {
+          c[j] = v[j];
+          if (pr) pr[j] = pre[j];
+        }
+      }
+    }
+  }
+}
+
+// acc[2][2] (wave's 64 x 64 result) -> LDS staging -> epilogue, one 32-row half at a time.  `smem_f` is the (now idle)
+// operand staging memory; each wave uses a private 32 x STG_LD f32 slice, so no workgroup barrier is needed.
+template <typename T>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& p, float* smem_f, f32x16 (&acc)[2][2], long long zoffC, int z,
+                                              int m0, int n0, int wid, int lane) {
+  float* stage = smem_f + wid * 32 * STG_LD;
+  const int wr = wid >> 1, wc = wid & 1, h = lane >> 5, li = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * STG_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+    epilogue_tile<T>(p, stage, zoffC, z, m0 + wr * 64 + i * 32, n0 + wc * 64, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 kernel
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128;
+constexpr int BK16 = 32, LD16 = 40;  // bf16: 32-deep K tile, LDS rows padded to 40 elements (80 B)
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// One operand tile (128 rows x 32 k) global -> registers.  Non-transposed: chunk = 8 consecutive k of one row.
+// Transposed: chunk = 8 consecutive rows of one k.
+template <bool TR>
+__device__ __forceinline__ void load_tile16(const unsigned short* base, long long ld, int rows, int K, int row0, int k0,
+                                            bool vec, int tid, uint4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    int r, k, nvalid;
+    const unsigned short* src;
+    if (!TR) {
+      r = row0 + (c >> 2);
+      k = k0 + (c & 3) * 8;
+      nvalid = (r < rows) ? min(8, K - k) : 0;
+      src = base + (long long)r * ld + k;
+    } else {
+      k = k0 + (c & 31);
+      r = row0 + (c >> 5) * 8;
+      nvalid = (k < K) ? min(8, rows - r) : 0;
+      src = base + (long long)k * ld + r;
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (nvalid >= 8 && vec) {
+      v = *(const uint4*)src;
+    } else if (nvalid > 0) {
+      unsigned short tmp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tmp[j] = (j < nvalid) ? src[j] : (unsigned short)0;
+      v.x = tmp[0] | ((unsigned)tmp[1] << 16); v.y = tmp[2] | ((unsigned)tmp[3] << 16);
+      v.z = tmp[4] | ((unsigned)tmp[5] << 16); v.w = tmp[6] | ((unsigned)tmp[7] << 16);
+    }
+    reg[i] = v;
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ void store_tile16(unsigned short* lds, int tid, const uint4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    if (!TR) {
+      *(uint4*)(lds + (c >> 2) * LD16 + (c & 3) * 8) = reg[i];
+    } else {
+      const int k = c & 31, r = (c >> 5) * 8;
+      const unsigned w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lds[(r + 2 * j) * LD16 + k] = (unsigned short)(w[j] & 0xFFFF);
+        lds[(r + 2 * j + 1) * LD16 + k] = (unsigned short)(w[j] >> 16);
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * 2 * BM * LD16];
+  unsigned short* As = smem;
+  unsigned short* Bs = smem + 2 * BM * LD16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int h = lane >> 5, li = lane & 31;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+  const unsigned short* A = (const unsigned short*)p.A + z1 * p.sA1 + z2 * p.sA2;
+  const unsigned short* B = (const unsigned short*)p.B + z1 * p.sB1 + z2 * p.sB2;
+  const long long zoffC = z1 * p.sC1 + z2 * p.sC2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[2], rb[2];
+  const int nk = (p.K + BK16 - 1) / BK16;
+  load_tile16<TA>(A, p.lda, p.M, p.K, m0, 0, p.a_vec, tid, ra);
+  load_tile16<TB>(B, p.ldb, p.N, p.K, n0, 0, p.b_vec, tid, rb);
+  store_tile16<TA>(As, tid, ra);
+  store_tile16<TB>(Bs, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      load_tile16<TA>(A, p.lda, p.M, p.K, m0, (t + 1) * BK16, p.a_vec, tid, ra);
+      load_tile16<TB>(B, p.ldb, p.N, p.K, n0, (t + 1) * BK16, p.b_vec, tid, rb);
+    }
+    const unsigned short* as = As + cur * BM * LD16;
+    const unsigned short* bs = Bs + cur * BM * LD16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *(const bf16x8_t*)(as + (wr * 64 + i * 32 + li) * LD16 + ks * 16 + h * 8);
+        b[i] = *(const bf16x8_t*)(bs + (wc * 64 + i * 32 + li) * LD16 + ks * 16 + h * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      store_tile16<TA>(As + (cur ^ 1) * BM * LD16, tid, ra);
+      store_tile16<TB>(Bs + (cur ^ 1) * BM * LD16, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  epilogue_wave<unsigned short>(p, (float*)smem, acc, zoffC, z, m0, n0, wid, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// f32 kernel (exact f32: each output is a k-ordered fmaf chain on the f32 matrix cores)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BK32 = 16, LD32 = 17;
+
+template <bool TR>
+__device__ __forceinline__ void load_tile32(const float* base, long long ld, int rows, int K, int row0, int k0, bool vec,
+                                            int tid, float4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    int r, k, nvalid;
+    const float* src;
+    if (!TR) {
+      r = row0 + (c >> 2);
+      k = k0 + (c & 3) * 4;
+      nvalid = (r < rows) ? min(4, K - k) : 0;
+      src = base + (long long)r * ld + k;
+    } else {
+      k = k0 + (c & 15);
+      r = row0 + (c >> 4) * 4;
+      nvalid = (k < K) ? min(4, rows - r) : 0;
+      src = base + (long long)k * ld + r;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && vec) {
+      v = *(const float4*)src;
+    } else if (nvalid > 0) {
+      v.x = src[0];
+      if (nvalid > 1) v.y = src[1];
+      if (nvalid > 2) v.z = src[2];
+      if (nvalid > 3) v.w = src[3];
+    }
+    reg[i] = v;
+  }
+}
+
+template <bool TR>
+__device__ __forceinline__ void store_tile32(float* lds, int tid, const float4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i;
+    const float w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    if (!TR) {
+      float* d = lds + (c >> 2) * LD32 + (c & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = w[j];
+    } else {
+      const int k = c & 15, r = (c >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds[(r + j) * LD32 + k] = w[j];
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * LD32];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LD32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int h = lane >> 5, li = lane & 31;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+  const float* A = (const float*)p.A + z1 * p.sA1 + z2 * p.sA2;
+  const float* B = (const float*)p.B + z1 * p.sB1 + z2 * p.sB2;
+  const long long zoffC = z1 * p.sC1 + z2 * p.sC2;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  const int nk = (p.K + BK32 - 1) / BK32;
+  load_tile32<TA>(A, p.lda, p.M, p.K, m0, 0, p.a_vec, tid, ra);
+  load_tile32<TB>(B, p.ldb, p.N, p.K, n0, 0, p.b_vec, tid, rb);
+  store_tile32<TA>(As, tid, ra);
+  store_tile32<TB>(Bs, tid, rb);
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) {
+      load_tile32<TA>(A, p.lda, p.M, p.K, m0, (t + 1) * BK32, p.a_vec, tid, ra);
+      load_tile32<TB>(B, p.ldb, p.N, p.K, n0, (t + 1) * BK32, p.b_vec, tid, rb);
+    }
+    const float* as = As + cur * BM * LD32;
+    const float* bs = Bs + cur * BM * LD32;
+#pragma unroll
+    for (int ks = 0; ks < BK32 / 2; ++ks) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = as[(wr * 64 + i * 32 + li) * LD32 + ks * 2 + h];
+        b[i] = bs[(wc * 64 + i * 32 + li) * LD32 + ks * 2 + h];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) {
+      store_tile32<TA>(As + (cur ^ 1) * BM * LD32, tid, ra);
+      store_tile32<TB>(Bs + (cur ^ 1) * BM * LD32, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  epilogue_wave<float>(p, smem, acc, zoffC, z, m0, n0, wid, lane);
+}
+
+template <typename K>
+int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const char* name) {
+  dim3 grid(sc_cdiv(a.N, BN), sc_cdiv(a.M, BM), nbatch);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream, a);
+  SC_LAUNCH_CHECK(name);
+  return SC_OK;
+}
+
+}  // namespace
+
+// dtype: 0 = f32, 1 = bf16 (A, B, aux, pre_out and -- unless out_f32 -- C share it).
+SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
+                   long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
+                   long long sB2, long long sC1, long long sC2, float alpha, const float* bias, int act, void* pre_out,
+                   const void* aux, long long ldaux, int aux_mode, float drop_p, unsigned long long seed,
+                   unsigned long long offset, int out_f32, int accumulate, hipStream_t stream) {
+  SC_CHECK_ARG(A && B && C, "sc_gemm: null operand");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_gemm: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && nb1 >= 1 && nb2 >= 1, "sc_gemm: bad sizes M=%d N=%d K=%d nb=%dx%d", M, N, K, nb1, nb2);
+  SC_CHECK_ARG((long long)nb1 * nb2 <= 65535, "sc_gemm: batch %lld too large", (long long)nb1 * nb2);
+  SC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? N : K) && ldc >= N, "sc_gemm: leading dimension too small");
+  SC_CHECK_ARG(aux_mode == AUX_NONE || aux, "sc_gemm: aux_mode %d without aux", aux_mode);
+  SC_CHECK_ARG(!accumulate || out_f32, "sc_gemm: accumulate needs an f32 output");
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_gemm: dropout p=%f", drop_p);
+  GemmArgs a{};
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.nb2 = nb2; a.sA1 = sA1; a.sA2 = sA2; a.sB1 = sB1; a.sB2 = sB2; a.sC1 = sC1; a.sC2 = sC2;
+  a.alpha = alpha; a.bias = bias; a.act = act; a.pre_out = pre_out; a.aux = aux; a.ldaux = ldaux; a.aux_mode = aux_mode;
+  a.drop_p = drop_p; a.seed = seed; a.offset = offset; a.out_f32 = out_f32; a.accumulate = accumulate;
+  const long long esz = dtype == 0 ? 4 : 2;
+  auto vec_ok = [&](const void* ptr, long long ld, long long s1, long long s2) {
+    return ((uintptr_t)ptr % 16 == 0) && ((ld * esz) % 16 == 0) && ((s1 * esz) % 16 == 0) && ((s2 * esz) % 16 == 0);
+  };
+  a.a_vec = vec_ok(A, lda, sA1, sA2);
+  a.b_vec = vec_ok(B, ldb, sB1, sB2);
+  {
+    const long long cesz = out_f32 ? 4 : esz;
+    auto ok = [&](const void* ptr, long long ld, long long e) {
+      return ptr == nullptr || (((uintptr_t)ptr % 16 == 0) && ((ld * e) % 16 == 0) && ((sC1 * e) % 16 == 0) && ((sC2 * e) % 16 == 0));
+    };
+    a.c_vec = ok(C, ldc, cesz) && ok(aux, ldaux, esz) && ok(pre_out, ldc, esz);
+    a.c_vec32 = ok(C, ldc, 4) && ok(aux, ldaux, esz);
+  }
+  const int nb = nb1 * nb2;
+  if (dtype == 1) {
+    if (!ta && !tb) return launch(gemm_bf16_kernel<false, false>, a, nb, stream, "gemm_bf16<NT>");
+    if (!ta && tb) return launch(gemm_bf16_kernel<false, true>, a, nb, stream, "gemm_bf16<NN>");
+    if (ta && !tb) return launch(gemm_bf16_kernel<true, false>, a, nb, stream, "gemm_bf16<TT>");
+    return launch(gemm_bf16_kernel<true, true>, a, nb, stream, "gemm_bf16<TN>");
+  }
+  if (!ta && !tb) return launch(gemm_f32_kernel<false, false>, a, nb, stream, "gemm_f32<NT>");
+  if (!ta && tb) return launch(gemm_f32_kernel<false, true>, a, nb, stream, "gemm_f32<NN>");
+  if (ta && !tb) return launch(gemm_f32_kernel<true, false>, a, nb, stream, "gemm_f32<TT>");
+  return launch(gemm_f32_kernel<true, true>, a, nb, stream, "gemm_f32<TN>");
+}

@@ -1,0 +1,453 @@
+// Row-wise kernels of the transformer path for gfx950 (one 64-lane wavefront per row, shuffle reductions, fp32 math):
+//   LayerNorm forward/backward   -- nn.LayerNorm(d, eps=1e-6) at speechain/module/transformer/encoder.py:97-98,115-141,
+//                                   decoder.py:90-92,122-173 and the final LN encoder.py:291-292,346-347
+//   masked softmax forward/backward -- masked_fill(-inf) + Softmax + Dropout at attention.py:88-95
+//   label-smoothed cross entropy -- log_softmax + gather + smoothing at speechain/criterion/cross_entropy.py:132-146
+//   column sums                  -- bias gradients of every Linear
+// Activations are f32 or bf16 (template T); statistics, gammas, losses and reductions are always f32.
+#include "sc_common.h"
+
+namespace {
+
+template <typename T> struct Row;
+template <> struct Row<float> {
+  static __device__ __forceinline__ float ld(const void* p, long long i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void st(void* p, long long i, float v) { ((float*)p)[i] = v; }
+};
+template <> struct Row<unsigned short> {
+  static __device__ __forceinline__ float ld(const void* p, long long i) { return sc_bf16_to_f32(((const unsigned short*)p)[i]); }
+  static __device__ __forceinline__ void st(void* p, long long i, float v) { ((unsigned short*)p)[i] = sc_f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33;
+  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---- LayerNorm ---------------------------------------------------------------------------------------------------
+constexpr int LN_MAX = 32;  // elements per lane kept in registers: D <= 64 * 32 = 2048
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const float* gamma, const float* beta, void* y,
+                                                            float* mean, float* rstd, long long R, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const long long base = row * D;
+  float v[NI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    v[i] = (k < D) ? Row<T>::ld(x, base + k) : 0.f;
+    s += v[i];
+  }
+  const float mu = sc_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    const float d = (k < D) ? v[i] - mu : 0.f;
+    q += d * d;
+  }
+  const float rs = rsqrtf(sc_wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    if (k < D) Row<T>::st(y, base + k, (v[i] - mu) * rs * gamma[k] + beta[k]);
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
+// dx for a strip of rows; per-workgroup partial dgamma / dbeta go to part[(2*blockIdx.x + {0,1}) * D + k]
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* x, const float* mean, const float* rstd,
+                                                            const float* gamma, void* dx, float* part, long long R, int D,
+                                                            int rows_per_block) {
+  extern __shared__ float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float dg[NI], db[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) dg[i] = db[i] = 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(R, r0 + rows_per_block);
+  for (long long row = r0 + wid; row < r1; row += 4) {
+    const long long base = row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float g[NI], xh[NI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = lane + 64 * i;
+      if (k < D) {
+        const float d = Row<T>::ld(dy, base + k);
+        xh[i] = (Row<T>::ld(x, base + k) - mu) * rs;
+        g[i] = d * gamma[k];
+        dg[i] += d * xh[i];
+        db[i] += d;
+        s1 += g[i];
+        s2 += g[i] * xh[i];
+      } else {
+        g[i] = xh[i] = 0.f;
+      }
+    }
+    s1 = sc_wave_sum(s1) / (float)D;
+    s2 = sc_wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = lane + 64 * i;
+      if (k < D) Row<T>::st(dx, base + k, rs * (g[i] - s1 - xh[i] * s2));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    if (k < D) {
+      red[(wid * 2 + 0) * D + k] = dg[i];
+      red[(wid * 2 + 1) * D + k] = db[i];
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < D; k += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[(w * 2 + 0) * D + k];
+      b += red[(w * 2 + 1) * D + k];
+    }
+    part[((long long)blockIdx.x * 2 + 0) * D + k] = a;
+    part[((long long)blockIdx.x * 2 + 1) * D + k] = b;
+  }
+}
+
+// out[j][k] = sum_p part[(p * nout + j) * D + k]   (deterministic second stage of column reductions)
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int P, int nout, int D, float* out0, float* out1) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= D) return;
+  for (int j = 0; j < nout; ++j) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[((long long)p * nout + j) * D + k];
+    (j == 0 ? out0 : out1)[k] = s;
+  }
+}
+
+// column sums of an (R, N) matrix with row stride ld: partial[blockIdx.y][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* x, long long R, int N, long long ld, int rows_per_block, float* part) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s = 0.f;
+  for (long long r = r0; r < r1; ++r) s += Row<T>::ld(x, r * ld + n);
+  part[(long long)blockIdx.y * N + n] = s;
+}
+
+// ---- masked softmax ------------------------------------------------------------------------------------------------
+constexpr int SM_MAX = 16;  // keys per lane in registers: Tk <= 1024
+
+struct SoftmaxArgs {
+  const void* S;   // (Z, Tq, ld) scores (already scaled)
+  void* P;         // (Z, Tq, ld) probabilities (may alias S)
+  void* Pd;        // (Z, Tq, ld) dropped probabilities or null
+  int Z, H, Tq, Tk;
+  long long ld;
+  const unsigned char* mask;  // bool (B, Tq|1, Tk) or null; batch = z / H
+  long long mask_b, mask_q;   // strides (mask_q = 0 broadcasts over queries)
+  int causal;
+  float drop_p;
+  unsigned long long seed, offset;
+};
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)p.Z * p.Tq) return;
+  const int z = (int)(row / p.Tq), q = (int)(row - (long long)z * p.Tq), b = z / p.H;
+  const long long base = row * p.ld;
+  const unsigned char* mrow = p.mask ? p.mask + b * p.mask_b + q * p.mask_q : nullptr;
+  float v[NI];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    bool ok = k < p.Tk;
+    if (ok && mrow) ok = mrow[k] != 0;
+    if (ok && p.causal) ok = k <= q;
+    v[i] = ok ? Row<T>::ld(p.S, base + k) : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = sc_wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    v[i] = (v[i] == -INFINITY) ? 0.f : expf(v[i] - mx);
+    s += v[i];
+  }
+  s = sc_wave_sum(s);
+  const float inv = s > 0.f ? 1.f / s : 0.f;  // a fully masked row yields zeros (torch would give NaN)
+  const float keep = 1.f / (1.f - p.drop_p);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    if (k < p.ld) {  // also zero the padding columns [Tk, ld) so they are inert as a GEMM operand
+      const float pr = (k < p.Tk) ? v[i] * inv : 0.f;
+      Row<T>::st(p.P, base + k, pr);
+      if (p.Pd) {
+        float d = pr;
+        if (p.drop_p > 0.f) d = (uniform01(p.seed, p.offset + base + k) < p.drop_p) ? 0.f : pr * keep;
+        Row<T>::st(p.Pd, base + k, d);
+      }
+    }
+  }
+}
+
+// dS = P * (dP - sum_k dP * P) * out_scale with dP = dPd * keepmask / (1 - p)
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const void* P, const void* dPd, void* dS, long long rows, int Tk,
+                                                          long long ld, float out_scale, float drop_p,
+                                                          unsigned long long seed, unsigned long long offset) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long base = row * ld;
+  const float keep = 1.f / (1.f - drop_p);
+  float pr[NI], dp[NI];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    if (k < Tk) {
+      pr[i] = Row<T>::ld(P, base + k);
+      float d = Row<T>::ld(dPd, base + k);
+      if (drop_p > 0.f) d = (uniform01(seed, offset + base + k) < drop_p) ? 0.f : d * keep;
+      dp[i] = d;
+      dot += d * pr[i];
+    } else {
+      pr[i] = dp[i] = 0.f;
+    }
+  }
+  dot = sc_wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = lane + 64 * i;
+    if (k < ld) Row<T>::st(dS, base + k, (k < Tk) ? pr[i] * (dp[i] - dot) * out_scale : 0.f);
+  }
+}
+
+// ---- cross entropy ---------------------------------------------------------------------------------------------------
+// one workgroup per row: online max / sum-exp / sum over V in a single read of the logits
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const void* logits, const long long* target, long long R, int V, long long ld,
+                                                     float inv_temp, float smoothing, float* row_loss, float* lse_out) {
+  __shared__ float sm[3][4];
+  const long long row = blockIdx.x;
+  const long long base = row * ld;
+  float mx = -INFINITY, se = 0.f, sx = 0.f;
+  for (int k = threadIdx.x; k < V; k += 256) {
+    const float x = Row<T>::ld(logits, base + k) * inv_temp;
+    sx += x;
+    if (x > mx) {
+      se = se * expf(mx - x) + 1.f;
+      mx = x;
+    } else {
+      se += expf(x - mx);
+    }
+  }
+  // wave then workgroup combine of (mx, se) pairs
+  const float wmx = sc_wave_max(mx);
+  se = sc_wave_sum(mx == -INFINITY ? 0.f : se * expf(mx - wmx));
+  sx = sc_wave_sum(sx);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wid] = wmx; sm[1][wid] = se; sm[2][wid] = sx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float gm = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+    float gs = 0.f, gx = 0.f;
+    for (int w = 0; w < 4; ++w) { gs += sm[1][w] * expf(sm[0][w] - gm); gx += sm[2][w]; }
+    const float lse = gm + logf(gs);
+    const long long t = target[row];
+    const float lp_t = Row<T>::ld(logits, base + t) * inv_temp - lse;
+    const float sum_lp = gx - (float)V * lse;
+    float loss = lp_t;
+    if (smoothing > 0.f) loss = lp_t * (1.f - smoothing) + sum_lp * (smoothing / (float)V);
+    row_loss[row] = -loss;
+    lse_out[row] = lse;
+  }
+}
+
+// dlogits[r][v] = grow[r] * inv_temp * (softmax - (1 - eps) * onehot - eps / V)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const void* logits, const long long* target, const float* lse, const float* grow,
+                                                     long long R, int V, long long ld, float inv_temp, float smoothing, void* dlogits) {
+  const long long row = blockIdx.x;
+  const long long base = row * ld;
+  const float g = grow[row] * inv_temp, l = lse[row];
+  const long long t = target[row];
+  const float sneg = smoothing / (float)V;
+  for (int k = threadIdx.x; k < V; k += 256) {
+    float d = 0.f;
+    if (g != 0.f) {
+      const float pr = expf(Row<T>::ld(logits, base + k) * inv_temp - l);
+      d = g * (pr - ((k == t) ? (1.f - smoothing) : 0.f) - sneg);
+    }
+    Row<T>::st(dlogits, base + k, d);
+  }
+}
+
+// row-wise logsumexp only (CTC): lse[r]
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_kernel(const void* logits, long long R, int V, long long ld, float* lse_out) {
+  __shared__ float sm[2][4];
+  const long long base = (long long)blockIdx.x * ld;
+  float mx = -INFINITY, se = 0.f;
+  for (int k = threadIdx.x; k < V; k += 256) {
+    const float x = Row<T>::ld(logits, base + k);
+    if (x > mx) { se = se * expf(mx - x) + 1.f; mx = x; } else { se += expf(x - mx); }
+  }
+  const float wmx = sc_wave_max(mx);
+  se = sc_wave_sum(mx == -INFINITY ? 0.f : se * expf(mx - wmx));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wid] = wmx; sm[1][wid] = se; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gm = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+    float gs = 0.f;
+    for (int w = 0; w < 4; ++w) gs += sm[1][w] * expf(sm[0][w] - gm);
+    lse_out[blockIdx.x] = gm + logf(gs);
+  }
+}
+
+}  // namespace
+
+#define SC_DISPATCH_TN(dtype, n, KERNEL, N0, N1, N2, ...)                                                  \
+  do {                                                                                                     \
+    if ((dtype) == 0) {                                                                                    \
+      if ((n) <= 64 * N0) hipLaunchKernelGGL((KERNEL<float, N0>), __VA_ARGS__);                            \
+      else if ((n) <= 64 * N1) hipLaunchKernelGGL((KERNEL<float, N1>), __VA_ARGS__);                       \
+      else hipLaunchKernelGGL((KERNEL<float, N2>), __VA_ARGS__);                                           \
+    } else {                                                                                               \
+      if ((n) <= 64 * N0) hipLaunchKernelGGL((KERNEL<unsigned short, N0>), __VA_ARGS__);                   \
+      else if ((n) <= 64 * N1) hipLaunchKernelGGL((KERNEL<unsigned short, N1>), __VA_ARGS__);              \
+      else hipLaunchKernelGGL((KERNEL<unsigned short, N2>), __VA_ARGS__);                                  \
+    }                                                                                                      \
+  } while (0)
+
+#define SC_DISPATCH_T(dtype, KERNEL, ...)                                        \
+  do {                                                                           \
+    if ((dtype) == 0) hipLaunchKernelGGL(KERNEL<float>, __VA_ARGS__);            \
+    else hipLaunchKernelGGL(KERNEL<unsigned short>, __VA_ARGS__);                \
+  } while (0)
+
+SC_API int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                            long long R, int D, float eps, hipStream_t stream) {
+  SC_CHECK_ARG(x && gamma && beta && y, "sc_layernorm_fwd: null pointer");
+  SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_fwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
+  SC_DISPATCH_TN(dtype, D, layernorm_fwd_kernel, 8, 16, 32, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, D, eps);
+  SC_LAUNCH_CHECK("layernorm_fwd_kernel");
+  return SC_OK;
+}
+
+SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
+  long long blocks = (R + 31) / 32;
+  if (blocks > 512) blocks = 512;
+  return blocks * 2 * D * (long long)sizeof(float);
+}
+
+SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            void* dx, float* dgamma, float* dbeta, long long R, int D, void* workspace, long long ws_bytes,
+                            hipStream_t stream) {
+  SC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "sc_layernorm_bwd: null pointer");
+  SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
+  SC_CHECK_ARG(ws_bytes >= sc_layernorm_bwd_workspace(R, D), "sc_layernorm_bwd: workspace too small");
+  long long blocks = (R + 31) / 32;
+  if (blocks > 512) blocks = 512;
+  const int rpb = (int)((R + blocks - 1) / blocks);
+  blocks = (R + rpb - 1) / rpb;
+  const size_t smem = (size_t)8 * D * sizeof(float);
+  SC_CHECK_ARG(smem <= 64 * 1024, "sc_layernorm_bwd: D too large for the LDS reduction");
+  SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
+                (float*)workspace, R, D, rpb);
+  SC_LAUNCH_CHECK("layernorm_bwd_kernel");
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 256)), dim3(256), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
+  SC_LAUNCH_CHECK("reduce_parts_kernel");
+  return SC_OK;
+}
+
+SC_API long long sc_colsum_workspace(long long R, int N) {
+  long long strips = (R + 255) / 256;
+  if (strips > 256) strips = 256;
+  return strips * N * (long long)sizeof(float);
+}
+
+SC_API int sc_colsum(int dtype, const void* x, long long R, int N, long long ld, float* out, void* workspace, long long ws_bytes,
+                     hipStream_t stream) {
+  SC_CHECK_ARG(x && out && workspace, "sc_colsum: null pointer");
+  SC_CHECK_ARG(R >= 1 && N >= 1 && ld >= N, "sc_colsum: bad sizes");
+  SC_CHECK_ARG(ws_bytes >= sc_colsum_workspace(R, N), "sc_colsum: workspace too small");
+  long long strips = (R + 255) / 256;
+  if (strips > 256) strips = 256;
+  const int rpb = (int)((R + strips - 1) / strips);
+  strips = (R + rpb - 1) / rpb;
+  SC_DISPATCH_T(dtype, colsum_kernel, dim3(sc_cdiv(N, 256), (unsigned)strips), dim3(256), 0, stream, x, R, N, ld, rpb, (float*)workspace);
+  SC_LAUNCH_CHECK("colsum_kernel");
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(N, 256)), dim3(256), 0, stream, (const float*)workspace, (int)strips, 1, N, out, out);
+  SC_LAUNCH_CHECK("reduce_parts_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, int H, int Tq, int Tk, long long ld,
+                          const unsigned char* mask, long long mask_b, long long mask_q, int causal, float drop_p,
+                          unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(S && P, "sc_softmax_fwd: null pointer");
+  SC_CHECK_ARG(Z >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && ld >= Tk, "sc_softmax_fwd: bad sizes");
+  SC_CHECK_ARG(ld <= 64 * SM_MAX, "sc_softmax_fwd: row length %lld > %d keys", ld, 64 * SM_MAX);
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_softmax_fwd: dropout p=%f", drop_p);
+  SoftmaxArgs a{S, P, Pd, Z, H, Tq, Tk, ld, mask, mask_b, mask_q, causal, drop_p, seed, offset};
+  const long long rows = (long long)Z * Tq;
+  SC_DISPATCH_TN(dtype, ld, softmax_fwd_kernel, 4, 8, 16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+  SC_LAUNCH_CHECK("softmax_fwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_softmax_bwd(int dtype, const void* P, const void* dPd, void* dS, long long rows, int Tk, long long ld, float out_scale,
+                          float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(P && dPd && dS, "sc_softmax_bwd: null pointer");
+  SC_CHECK_ARG(rows >= 1 && Tk >= 1 && ld >= Tk && ld <= 64 * SM_MAX, "sc_softmax_bwd: bad sizes");
+  SC_DISPATCH_TN(dtype, ld, softmax_bwd_kernel, 4, 8, 16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, P, dPd, dS, rows, Tk, ld, out_scale,
+                drop_p, seed, offset);
+  SC_LAUNCH_CHECK("softmax_bwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_ce_fwd(int dtype, const void* logits, const long long* target, long long R, int V, long long ld, float temperature,
+                     float smoothing, float* row_loss, float* lse, hipStream_t stream) {
+  SC_CHECK_ARG(logits && target && row_loss && lse, "sc_ce_fwd: null pointer");
+  SC_CHECK_ARG(R >= 1 && V >= 1 && ld >= V && temperature > 0.f, "sc_ce_fwd: bad sizes");
+  SC_DISPATCH_T(dtype, ce_fwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, target, R, V, ld, 1.f / temperature, smoothing, row_loss, lse);
+  SC_LAUNCH_CHECK("ce_fwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_ce_bwd(int dtype, const void* logits, const long long* target, const float* lse, const float* grow, long long R, int V,
+                     long long ld, float temperature, float smoothing, void* dlogits, hipStream_t stream) {
+  SC_CHECK_ARG(logits && target && lse && grow && dlogits, "sc_ce_bwd: null pointer");
+  SC_CHECK_ARG(R >= 1 && V >= 1 && ld >= V && temperature > 0.f, "sc_ce_bwd: bad sizes");
+  SC_DISPATCH_T(dtype, ce_bwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, target, lse, grow, R, V, ld, 1.f / temperature, smoothing, dlogits);
+  SC_LAUNCH_CHECK("ce_bwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream) {
+  SC_CHECK_ARG(logits && lse, "sc_row_lse: null pointer");
+  SC_CHECK_ARG(R >= 1 && V >= 1 && ld >= V, "sc_row_lse: bad sizes");
+  SC_DISPATCH_T(dtype, row_lse_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, R, V, ld, lse);
+  SC_LAUNCH_CHECK("row_lse_kernel");
+  return SC_OK;
+}

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
     float scale;
     if (t < p.warp_pos) { base = 0; in_len = p.warp_center; dst = t; scale = p.scale_l; }
     else { base = p.warp_center; in_len = p.tmin - p.warp_center; dst = t - p.warp_pos; scale = p.scale_r; }
-    const float real = scale * (float)dst;
+    const float real = __fmul_rn(scale, (float)dst);  // no FMA contraction: aten rounds the product first
     int i0 = (int)floorf(real);
     if (i0 > in_len - 1) i0 = in_len - 1;
     float lam = real - (float)i0;

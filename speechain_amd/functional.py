@@ -1,0 +1,618 @@
+"""Autograd-aware wrappers over the C ABI (include/speechain_amd.h) -- the ONLY place where kernels are launched for
+the transformer path.  Every function here requires device tensors and calls the HIP library; there is no torch
+fallback.  Activations are float32 (exact parity mode) or bfloat16 (training mode); parameters stay float32 masters
+and gradients of parameters are produced in float32.
+
+Stateless dropout: each dropout site draws (seed, offset) from :class:`DropoutState`; the backward pass regenerates the
+identical keep-mask from the saved pair, so no mask tensor is stored.
+"""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from speechain_amd._lib import lib, require_gpu, stream
+
+ACT = {None: 0, "none": 0, "ReLU": 1, "GELU": 2}
+F32, BF16 = 0, 1
+
+
+def dcode(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"speechain_amd kernels take float32 or bfloat16 activations, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor], elem_offset: int = 0):
+    if t is None:
+        return None
+    return t.data_ptr() + elem_offset * t.element_size()
+
+
+def _up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class DropoutState:
+    """Process-wide counter-based generator state: seed follows torch.manual_seed, offsets never repeat."""
+
+    seed = None
+    offset = 0
+
+    @classmethod
+    def next(cls, numel: int) -> Tuple[int, int]:
+        if cls.seed is None:
+            cls.seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        off = cls.offset
+        cls.offset += int(numel)
+        return cls.seed, off
+
+    @classmethod
+    def reset(cls, seed: int):
+        cls.seed, cls.offset = seed & 0x7FFFFFFFFFFFFFFF, 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compute dtype policy and cached low-precision copies of the float32 master weights
+# ---------------------------------------------------------------------------------------------------------------------
+
+_compute_dtype = None  # None: follow torch autocast (bf16 when autocast is on, else f32)
+
+
+def set_compute_dtype(dtype: Optional[torch.dtype]):
+    """Force the activation dtype of the speechain_amd modules (torch.float32 / torch.bfloat16); None = follow autocast."""
+    global _compute_dtype
+    assert dtype in (None, torch.float32, torch.bfloat16)
+    _compute_dtype = dtype
+
+
+def compute_dtype() -> torch.dtype:
+    if _compute_dtype is not None:
+        return _compute_dtype
+    return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+
+def to_compute(x: torch.Tensor, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Differentiable cast of an activation to the compute dtype (a HIP cast kernel; identity when already there)."""
+    dtype = dtype or compute_dtype()
+    if x.dtype == dtype:
+        return x
+    return _Cast.apply(x, dtype)
+
+
+def raw_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    x = x.contiguous()
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    lib.call("sc_cast", dcode(x), BF16 if dtype == torch.bfloat16 else F32, _p(x), _p(out), x.numel(), stream())
+    return out
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        require_gpu(x, "cast")
+        ctx.in_dtype = x.dtype
+        return raw_cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return raw_cast(g, ctx.in_dtype), None
+
+
+class _WeightCache:
+    """(fused) compute-dtype copies of parameters, refreshed when a parameter's version counter moves."""
+
+    def __init__(self):
+        self.store = {}
+
+    def fused(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+        """Rows of all `params` (each (n_i, K) float32) stacked into one (sum n_i, K) matrix of `dtype`."""
+        if len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
+            return params[0].detach()
+        cacheable = all(p.is_leaf for p in params)  # derived tensors (e.g. reshaped conv weights) are cast on the fly
+        key = (tuple(id(p) for p in params), dtype)
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self.store.get(key) if cacheable else None
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        K = params[0].size(1)
+        rows = sum(p.size(0) for p in params)
+        buf = hit[1] if hit is not None else torch.empty(rows, K, dtype=dtype, device=params[0].device)
+        r = 0
+        for p in params:
+            src = p.detach().contiguous()
+            lib.call("sc_cast", F32, BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r * K), src.numel(), stream())
+            r += p.size(0)
+        if cacheable:
+            self.store[key] = (ver, buf)
+        return buf
+
+    def vector(self, params: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+        """float32 concatenation of bias vectors (None if there is no bias)."""
+        if params[0] is None:
+            return None
+        if len(params) == 1:
+            return params[0].detach()
+        key = (tuple(id(p) for p in params), "vec")
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        buf = torch.cat([p.detach() for p in params])
+        if all(p.is_leaf for p in params):
+            self.store[key] = (ver, buf)
+        return buf
+
+
+weights = _WeightCache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# raw GEMM launcher
+# ---------------------------------------------------------------------------------------------------------------------
+
+def gemm(code: int, A, B, C, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, ta=0, tb=0, nb=(1, 1), sA=(0, 0),
+         sB=(0, 0), sC=(0, 0), alpha=1.0, bias=None, act=0, pre_out=None, aux=None, ldaux=0, aux_mode=0, drop=(0.0, 0, 0),
+         out_f32=False, accumulate=False):
+    """A, B, C, pre_out, aux: raw device addresses (ints); see sc_gemm in include/speechain_amd.h."""
+    lib.call("sc_gemm", code, ta, tb, A, B, C, M, N, K, lda, ldb, ldc, nb[0], nb[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
+             float(alpha), _p(bias), act, pre_out, aux, ldaux, aux_mode, float(drop[0]), int(drop[1]), int(drop[2]),
+             1 if out_f32 else 0, 1 if accumulate else 0, stream())
+
+
+def _colsum(x2d: torch.Tensor) -> torch.Tensor:
+    R, N = x2d.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(lib.value("sc_colsum_workspace", R, N), dtype=torch.uint8, device=x2d.device)
+    lib.call("sc_colsum", dcode(x2d), _p(x2d), R, N, x2d.stride(0), _p(out), _p(ws), ws.numel(), stream())
+    return out
+
+
+def _dropout_apply(x: torch.Tensor, p: float, seed: int, offset: int) -> torch.Tensor:
+    if p <= 0.0:
+        return x
+    y = torch.empty_like(x)
+    lib.call("sc_dropout", dcode(x), _p(x), _p(y), x.numel(), 1.0, float(p), seed, offset, stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Linear:  y = dropout(x W^T + b) [+ residual]      (W may be several parameters stacked along the output dim)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, drop_p, nw, *wb):
+        ws, bs = list(wb[:nw]), list(wb[nw:])
+        require_gpu(x, "linear")
+        x2 = x.reshape(-1, x.size(-1))
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        code = dcode(x2)
+        W = weights.fused(ws, x2.dtype)
+        b = weights.vector(bs)
+        N = W.size(0)
+        y = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
+        seed, off = DropoutState.next(M * N) if drop_p > 0 else (0, 0)
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(M, N)
+            if not res2.is_contiguous():
+                res2 = res2.contiguous()
+        gemm(code, _p(x2), _p(W), _p(y), M, N, K, K, K, N, bias=b, aux=_p(res2), ldaux=N, aux_mode=1 if res2 is not None else 0,
+             drop=(drop_p, seed, off))
+        ctx.save_for_backward(x2, *ws)
+        ctx.meta = (x.shape, drop_p, seed, off, [w.size(0) for w in ws], [bb is not None for bb in bs], residual is not None)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, *ws = ctx.saved_tensors
+        xshape, drop_p, seed, off, rows, has_b, has_res = ctx.meta
+        M, K = x2.shape
+        N = sum(rows)
+        code = dcode(x2)
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy if has_res else None
+        dz = _dropout_apply(dy2, drop_p, seed, off)
+        W = weights.fused(ws, x2.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            gemm(code, _p(dz), _p(W), _p(dx), M, K, N, N, K, K, tb=1)  # dx = dz W
+            dx = dx.reshape(xshape)
+        dW = torch.empty(N, K, dtype=torch.float32, device=x2.device)
+        gemm(code, _p(dz), _p(x2), _p(dW), N, K, M, N, K, K, ta=1, tb=1, out_f32=True)  # dW = dz^T x
+        dws = list(dW.split(rows, dim=0))
+        dbs = [None] * len(rows)
+        if any(has_b):
+            db = _colsum(dz)
+            dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
+        return (dx, dres, None, None, *dws, *dbs)
+
+
+def linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], drop_p: float = 0.0,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _Linear.apply(x, residual, float(drop_p), len(ws), *ws, *bs)
+
+
+class _LinearAct(torch.autograd.Function):
+    """h = dropout(act(x W^T + b)) with the pre-activation kept for the backward pass (conv-type FFN in-layer)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, drop_p):
+        require_gpu(x, "linear")
+        x2 = x.reshape(-1, x.size(-1))
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        code = dcode(x2)
+        W = weights.fused([w], x2.dtype)
+        N = W.size(0)
+        pre = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
+        h = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
+        seed, off = DropoutState.next(M * N) if drop_p > 0 else (0, 0)
+        gemm(code, _p(x2), _p(W), _p(h), M, N, K, K, K, N, bias=b.detach() if b is not None else None, act=act, pre_out=_p(pre),
+             drop=(drop_p, seed, off))
+        ctx.save_for_backward(x2, pre, w)
+        ctx.meta = (x.shape, act, drop_p, seed, off, b is not None)
+        return h.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dh):
+        x2, pre, w = ctx.saved_tensors
+        xshape, act, drop_p, seed, off, has_b = ctx.meta
+        M, K = x2.shape
+        N = pre.size(1)
+        code = dcode(x2)
+        dh2 = dh.reshape(M, N)
+        if not dh2.is_contiguous():
+            dh2 = dh2.contiguous()
+        dpre = torch.empty_like(pre)
+        lib.call("sc_act_bwd", code, _p(dh2), _p(pre), _p(dpre), dpre.numel(), act, float(drop_p), seed, off, stream())
+        W = weights.fused([w], x2.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            gemm(code, _p(dpre), _p(W), _p(dx), M, K, N, N, K, K, tb=1)
+            dx = dx.reshape(xshape)
+        dW = torch.empty(N, K, dtype=torch.float32, device=x2.device)
+        gemm(code, _p(dpre), _p(x2), _p(dW), N, K, M, N, K, K, ta=1, tb=1, out_f32=True)
+        db = _colsum(dpre) if has_b else None
+        return dx, dW, db, None, None
+
+
+def linear_act(x, w, b, activation: str, drop_p: float = 0.0):
+    if activation not in ACT:
+        raise NotImplementedError(f"speechain_amd feed-forward implements ReLU and GELU, got {activation}")
+    return _LinearAct.apply(x, w, b, ACT[activation], float(drop_p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Position-wise feed-forward:  y = dropout_res( dropout_h(act(x W1^T + b1)) W2^T + b2 ) [+ residual]
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _FFN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, act, p_h, p_res):
+        require_gpu(x, "feed-forward")
+        x2 = x.reshape(-1, x.size(-1))
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        code = dcode(x2)
+        W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
+        Fd = W1.size(0)
+        h_pre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
+        h = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
+        s1, o1 = DropoutState.next(M * Fd) if p_h > 0 else (0, 0)
+        gemm(code, _p(x2), _p(W1), _p(h), M, Fd, K, K, K, Fd, bias=b1.detach() if b1 is not None else None, act=act,
+             pre_out=_p(h_pre), drop=(p_h, s1, o1))
+        y = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+        s2, o2 = DropoutState.next(M * K) if p_res > 0 else (0, 0)
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(M, K)
+            if not res2.is_contiguous():
+                res2 = res2.contiguous()
+        gemm(code, _p(h), _p(W2), _p(y), M, K, Fd, Fd, Fd, K, bias=b2.detach() if b2 is not None else None, aux=_p(res2), ldaux=K,
+             aux_mode=1 if res2 is not None else 0, drop=(p_res, s2, o2))
+        ctx.save_for_backward(x2, h_pre, h, w1, w2)
+        ctx.meta = (x.shape, act, p_h, s1, o1, p_res, s2, o2, b1 is not None, b2 is not None, residual is not None)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h_pre, h, w1, w2 = ctx.saved_tensors
+        xshape, act, p_h, s1, o1, p_res, s2, o2, has_b1, has_b2, has_res = ctx.meta
+        M, K = x2.shape
+        Fd = h.size(1)
+        code = dcode(x2)
+        dy2 = dy.reshape(M, K)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dz = _dropout_apply(dy2, p_res, s2, o2)
+        W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
+        dW2 = torch.empty(K, Fd, dtype=torch.float32, device=x2.device)
+        gemm(code, _p(dz), _p(h), _p(dW2), K, Fd, M, K, Fd, Fd, ta=1, tb=1, out_f32=True)
+        db2 = _colsum(dz) if has_b2 else None
+        # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
+        dpre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
+        gemm(code, _p(dz), _p(W2), _p(dpre), M, Fd, K, K, Fd, Fd, tb=1, act=act, aux=_p(h_pre), ldaux=Fd, aux_mode=2,
+             drop=(p_h, s1, o1))
+        dW1 = torch.empty(Fd, K, dtype=torch.float32, device=x2.device)
+        gemm(code, _p(dpre), _p(x2), _p(dW1), Fd, K, M, Fd, K, K, ta=1, tb=1, out_f32=True)
+        db1 = _colsum(dpre) if has_b1 else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            gemm(code, _p(dpre), _p(W1), _p(dx), M, K, Fd, Fd, K, K, tb=1)
+            dx = dx.reshape(xshape)
+        return dx, (dy if has_res else None), dW1, db1, dW2, db2, None, None, None
+
+
+def ffn(x, w1, b1, w2, b2, activation: str, p_hidden: float = 0.0, p_res: float = 0.0, residual=None):
+    if activation not in ACT:
+        raise NotImplementedError(f"speechain_amd feed-forward implements ReLU and GELU, got {activation}")
+    return _FFN.apply(x, residual, w1, b1, w2, b2, ACT[activation], float(p_hidden), float(p_res))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_gpu(x, "layer norm")
+        D = x.size(-1)
+        x2 = x.reshape(-1, D)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        R = x2.size(0)
+        y = torch.empty_like(x2)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        lib.call("sc_layernorm_fwd", dcode(x2), _p(x2), _p(gamma.detach()), _p(beta.detach()), _p(y), _p(mean), _p(rstd), R, D,
+                 float(eps), stream())
+        ctx.save_for_backward(x2, mean, rstd, gamma)
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        R, D = x2.shape
+        dy2 = dy.reshape(R, D)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = torch.empty_like(x2)
+        dg = torch.empty(D, dtype=torch.float32, device=x2.device)
+        db = torch.empty(D, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(lib.value("sc_layernorm_bwd_workspace", R, D), dtype=torch.uint8, device=x2.device)
+        lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
+                 _p(ws), ws.numel(), stream())
+        return dx.reshape(ctx.xshape), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps: float):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Scaled dot-product attention core on head-interleaved buffers
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _AttnCore(torch.autograd.Function):
+    """q_buf (B, Tq, nq*d) and kv_buf (B, Tk, nkv*d) hold projections side by side along the last dim; q/k/v are the
+    d-wide column blocks iq / ik / iv of those buffers (for self-attention q_buf IS kv_buf).  Heads are the dh-wide
+    column groups inside a block.  Returns the merged-head context (B, Tq, d) and the probabilities (B, H, Tq, Tk)."""
+
+    @staticmethod
+    def forward(ctx, q_buf, kv_buf, same, iq, ik, iv, H, d, mask, causal, scale, drop_p):
+        require_gpu(q_buf, "attention")
+        if same:
+            kv_buf = q_buf
+        B, Tq = q_buf.shape[:2]
+        Tk = kv_buf.size(1)
+        dh = d // H
+        code = dcode(q_buf)
+        dt, dev = q_buf.dtype, q_buf.device
+        ldq, ldk = q_buf.stride(1), kv_buf.stride(1)
+        sqb, skb = q_buf.stride(0), kv_buf.stride(0)
+        ld = _up(Tk, 8)
+        Z = B * H
+        S = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
+        # S = scale * Q K^T
+        gemm(code, _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(S), Tq, Tk, dh, ldq, ldk, ld, nb=(B, H), sA=(sqb, dh), sB=(skb, dh),
+             sC=(H * Tq * ld, Tq * ld), alpha=scale)
+        m8 = mb = mq = None
+        if mask is not None:
+            m8 = mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask
+            m8 = m8.contiguous()
+            mb = m8.stride(0)
+            mq = m8.stride(1) if m8.size(1) > 1 else 0
+        Pd = None
+        seed = off = 0
+        if drop_p > 0:
+            Pd = torch.empty_like(S)
+            seed, off = DropoutState.next(S.numel())
+        lib.call("sc_softmax_fwd", code, _p(S), _p(S), _p(Pd), Z, H, Tq, Tk, ld, _p(m8), mb or 0, mq or 0, 1 if causal else 0,
+                 float(drop_p), seed, off, stream())
+        P = S
+        Pv = Pd if Pd is not None else P
+        out = torch.empty(B, Tq, d, dtype=dt, device=dev)
+        # ctx = Pd V  (V rows are keys: contraction index strided -> tb=1)
+        gemm(code, _p(Pv), _p(kv_buf, iv * d), _p(out), Tq, dh, Tk, ld, ldk, d, tb=1, nb=(B, H), sA=(H * Tq * ld, Tq * ld),
+             sB=(skb, dh), sC=(Tq * d, dh))
+        ctx.save_for_backward(q_buf, kv_buf, P, Pv)
+        ctx.meta = (same, iq, ik, iv, H, d, scale, drop_p, seed, off, ld)
+        probs = P.view(B, H, Tq, ld)[..., :Tk]
+        ctx.mark_non_differentiable(probs)
+        return out, probs
+
+    @staticmethod
+    def backward(ctx, dout, _dprobs):
+        q_buf, kv_buf, P, Pv = ctx.saved_tensors
+        same, iq, ik, iv, H, d, scale, drop_p, seed, off, ld = ctx.meta
+        B, Tq = q_buf.shape[:2]
+        Tk = kv_buf.size(1)
+        dh = d // H
+        code = dcode(q_buf)
+        dt, dev = q_buf.dtype, q_buf.device
+        Z = B * H
+        ldq, ldk = q_buf.stride(1), kv_buf.stride(1)
+        sqb, skb = q_buf.stride(0), kv_buf.stride(0)
+        dout = dout.contiguous()
+        dq_buf = torch.zeros_like(q_buf) if q_buf.size(-1) > (3 * d if same else d) else torch.empty_like(q_buf)
+        dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
+        zs = (H * Tq * ld, Tq * ld)
+        # dPd = dout V^T
+        dP = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
+        gemm(code, _p(dout), _p(kv_buf, iv * d), _p(dP), Tq, Tk, dh, d, ldk, ld, nb=(B, H), sA=(Tq * d, dh), sB=(skb, dh), sC=zs)
+        # dV = Pd^T dout
+        gemm(code, _p(Pv), _p(dout), _p(dkv_buf, iv * d), Tk, dh, Tq, ld, d, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H), sA=zs,
+             sB=(Tq * d, dh), sC=(dkv_buf.stride(0), dh))
+        # dS (w.r.t. the unscaled products) = scale * P * (dP - rowsum(dP * P)), written in place over dP
+        lib.call("sc_softmax_bwd", code, _p(P), _p(dP), _p(dP), Z * Tq, Tk, ld, float(scale), float(drop_p), seed, off, stream())
+        # dQ = dS K ;  dK = dS^T Q
+        gemm(code, _p(dP), _p(kv_buf, ik * d), _p(dq_buf, iq * d), Tq, dh, Tk, ld, ldk, dq_buf.stride(1), tb=1, nb=(B, H), sA=zs,
+             sB=(skb, dh), sC=(dq_buf.stride(0), dh))
+        gemm(code, _p(dP), _p(q_buf, iq * d), _p(dkv_buf, ik * d), Tk, dh, Tq, ld, ldq, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H),
+             sA=zs, sB=(sqb, dh), sC=(dkv_buf.stride(0), dh))
+        return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
+
+
+def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, scale, drop_p):
+    same = kv_buf is None or kv_buf is q_buf
+    return _AttnCore.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
+                           float(drop_p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Positional encoding add
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _PosEnc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, alpha, xscale, drop_p):
+        require_gpu(x, "positional encoding")
+        x = x.contiguous()
+        B, T, D = x.shape
+        y = torch.empty_like(x)
+        seed, off = DropoutState.next(x.numel()) if drop_p > 0 else (0, 0)
+        tab = table.reshape(-1, D)
+        lib.call("sc_posenc_fwd", dcode(x), _p(x), _p(tab), _p(alpha.detach()) if alpha is not None else None, float(xscale), _p(y),
+                 B, T, D, float(drop_p), seed, off, stream())
+        ctx.meta = (xscale, drop_p, seed, off, alpha is not None, T, D)
+        if alpha is not None:
+            ctx.save_for_backward(tab)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xscale, drop_p, seed, off, has_alpha, T, D = ctx.meta
+        dy = dy.contiguous()
+        dz = _dropout_apply(dy, drop_p, seed, off)  # gradient w.r.t. (x * xscale + table * alpha)
+        dalpha = None
+        if has_alpha:
+            (tab,) = ctx.saved_tensors
+            dalpha = (dz.float() * tab[:T]).sum()  # scalar parameter of the TTS recipes: a device-side reduction
+        if xscale != 1.0:
+            dx = torch.empty_like(dz)
+            lib.call("sc_dropout", dcode(dz), _p(dz), _p(dx), dz.numel(), float(xscale), 0.0, 0, 0, stream())
+        else:
+            dx = dz
+        return dx, None, dalpha, None, None
+
+
+def posenc_add(x, table, alpha, xscale: float, drop_p: float):
+    return _PosEnc.apply(x, table, alpha, float(xscale), float(drop_p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Losses
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _CrossEntropyRows(torch.autograd.Function):
+    """Per-token losses (R,) float32 of (R, V) logits; masking / sentence sums / means stay tiny torch ops on (R,)."""
+
+    @staticmethod
+    def forward(ctx, logits2, target, smoothing, temperature):
+        require_gpu(logits2, "cross entropy")
+        logits2 = logits2.contiguous()
+        R, V = logits2.shape
+        target = target.contiguous()
+        row_loss = torch.empty(R, dtype=torch.float32, device=logits2.device)
+        lse = torch.empty(R, dtype=torch.float32, device=logits2.device)
+        lib.call("sc_ce_fwd", dcode(logits2), _p(logits2), _p(target), R, V, V, float(temperature), float(smoothing), _p(row_loss),
+                 _p(lse), stream())
+        ctx.save_for_backward(logits2, target, lse)
+        ctx.meta = (smoothing, temperature)
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, grow):
+        logits2, target, lse = ctx.saved_tensors
+        smoothing, temperature = ctx.meta
+        R, V = logits2.shape
+        d = torch.empty_like(logits2)
+        grow = grow.float().contiguous()
+        lib.call("sc_ce_bwd", dcode(logits2), _p(logits2), _p(target), _p(lse), _p(grow), R, V, V, float(temperature), float(smoothing),
+                 _p(d), stream())
+        return d, None, None, None
+
+
+def cross_entropy_rows(logits2, target, smoothing: float, temperature: float = 1.0):
+    return _CrossEntropyRows.apply(logits2, target, float(smoothing), float(temperature))
+
+
+class _CTC(torch.autograd.Function):
+    """Per-utterance CTC negative log-likelihood (B,) float32 with zero_infinity handling."""
+
+    @staticmethod
+    def forward(ctx, logits, in_len, tgt, tgt_len, blank, zero_infinity):
+        require_gpu(logits, "CTC")
+        logits = logits.contiguous()
+        B, T, V = logits.shape
+        dev = logits.device
+        in_len = in_len.to(device=dev, dtype=torch.int64).contiguous()
+        tgt_len = tgt_len.to(device=dev, dtype=torch.int64).contiguous()
+        tgt = tgt.to(device=dev, dtype=torch.int64)
+        assert tgt.stride(1) == 1
+        Smax = 2 * tgt.size(1) + 1
+        lse = torch.empty(B * T, dtype=torch.float32, device=dev)
+        lib.call("sc_row_lse", dcode(logits), _p(logits), B * T, V, V, _p(lse), stream())
+        alpha = torch.empty(B, T, Smax, dtype=torch.float32, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        lib.call("sc_ctc_fwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax,
+                 blank, _p(alpha), _p(nll), stream())
+        ctx.save_for_backward(logits, lse, in_len, tgt, tgt_len, alpha, nll)
+        ctx.meta = (blank, zero_infinity, Smax)
+        if zero_infinity:
+            return torch.where(torch.isinf(nll), torch.zeros_like(nll), nll)
+        return nll.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, in_len, tgt, tgt_len, alpha, nll = ctx.saved_tensors
+        blank, zero_infinity, Smax = ctx.meta
+        B, T, V = logits.shape
+        gscale = g.float().contiguous()
+        if zero_infinity:
+            gscale = torch.where(torch.isinf(nll), torch.zeros_like(gscale), gscale)
+        grad = torch.empty_like(logits)
+        lib.call("sc_ctc_bwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax, blank,
+                 _p(alpha), _p(nll), _p(gscale), _p(grad), stream())
+        return grad, None, None, None, None, None
+
+
+def ctc_nll(logits, in_len, tgt, tgt_len, blank: int = 0, zero_infinity: bool = True):
+    return _CTC.apply(logits, in_len, tgt, tgt_len, int(blank), bool(zero_infinity))

@@ -1,0 +1,106 @@
+"""GPU: the batched GEMM entry point (sc_gemm) against torch fp32/fp64 matmul -- all operand layouts, both dtypes,
+ragged shapes, batch strides and every epilogue mode.  fp32 mode must be exact-f32 accurate; bf16 within bf16 rounding."""
+import math
+
+import pytest
+import torch
+
+from speechain_amd import functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g)).to(dtype).cuda()
+
+
+def _tol(dtype, K):
+    return dict(atol=1e-4 * math.sqrt(K / 64), rtol=1e-5) if dtype == torch.float32 else dict(atol=0.06 * math.sqrt(K / 64), rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 75, 100), (33, 257, 31), (7968 // 8, 512, 512), (5, 5000, 64)])
+def test_layouts_and_ragged_shapes(dtype, ta, tb, M, N, K):
+    A = _mk((K, M) if ta else (M, K), dtype, 1)
+    B = _mk((K, N) if tb else (N, K), dtype, 2)
+    C = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    Fn.gemm(Fn.dcode(A), Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, A.stride(0), B.stride(0), N, ta=ta, tb=tb)
+    opA = A.double().t() if ta else A.double()
+    opB = B.double().t() if tb else B.double()
+    ref = opA @ opB.t()
+    assert torch.allclose(C.double(), ref, **_tol(dtype, K)), float((C.double() - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_head_strides(dtype):
+    """Q K^T on head-interleaved (B, T, 3d) buffers, as the attention core issues it."""
+    Bn, T, H, dh = 3, 37, 4, 16
+    d = H * dh
+    qkv = _mk((Bn, T, 3 * d), dtype, 3)
+    ld = 40
+    S = torch.zeros(Bn * H, T, ld, dtype=dtype, device="cuda")
+    Fn.gemm(Fn.dcode(qkv), Fn._p(qkv, 0), Fn._p(qkv, d), Fn._p(S), T, T, dh, 3 * d, 3 * d, ld, nb=(Bn, H), sA=(T * 3 * d, dh),
+            sB=(T * 3 * d, dh), sC=(H * T * ld, T * ld), alpha=0.25)
+    q = qkv[..., :d].view(Bn, T, H, dh).transpose(1, 2).double()
+    k = qkv[..., d:2 * d].view(Bn, T, H, dh).transpose(1, 2).double()
+    ref = (q @ k.transpose(2, 3)) * 0.25
+    got = S.view(Bn, H, T, ld)[..., :T].double()
+    assert torch.allclose(got, ref, **_tol(dtype, dh))
+    assert float(S.view(Bn, H, T, ld)[..., T:].abs().max()) == 0.0  # padding columns untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_epilogues(dtype, act):
+    M, N, K = 150, 200, 96
+    A, B = _mk((M, K), dtype, 4), _mk((N, K), dtype, 5)
+    bias = _mk((N,), torch.float32, 6)
+    res = _mk((M, N), dtype, 7)
+    C = torch.empty(M, N, dtype=dtype, device="cuda")
+    pre = torch.empty(M, N, dtype=dtype, device="cuda")
+    Fn.gemm(Fn.dcode(A), Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, bias=bias, act=act, pre_out=Fn._p(pre), aux=Fn._p(res),
+            ldaux=N, aux_mode=1, alpha=0.5)
+    z = 0.5 * (A.double() @ B.double().t()) + bias.double()
+    f = [lambda t: t, torch.relu, lambda t: torch.nn.functional.gelu(t)][act]
+    ref = f(z) + res.double()
+    tol = _tol(dtype, K)
+    assert torch.allclose(pre.double(), z, **tol)
+    assert torch.allclose(C.double(), ref, **tol)
+    # activation-gradient epilogue: out = (A B^T) * act'(aux)
+    G = torch.empty(M, N, dtype=dtype, device="cuda")
+    Fn.gemm(Fn.dcode(A), Fn._p(A), Fn._p(B), Fn._p(G), M, N, K, K, K, N, act=act, aux=Fn._p(pre), ldaux=N, aux_mode=2)
+    zz = pre.double().requires_grad_()
+    (gact,) = torch.autograd.grad(f(zz).sum(), zz)
+    ref_g = (A.double() @ B.double().t()) * gact
+    assert torch.allclose(G.double(), ref_g, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_f32_output_and_accumulate(dtype):
+    M, N, K = 64, 96, 333
+    A, B = _mk((K, M), dtype, 8), _mk((K, N), dtype, 9)
+    C = torch.ones(M, N, dtype=torch.float32, device="cuda")
+    Fn.gemm(Fn.dcode(A), Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, M, N, N, ta=1, tb=1, out_f32=True, accumulate=True)
+    ref = 1.0 + A.double().t() @ B.double()
+    assert torch.allclose(C.double(), ref, **_tol(dtype, K))
+
+
+def test_dropout_epilogue_is_reproducible_and_unbiased():
+    M, N, K = 256, 512, 64
+    A, B = _mk((M, K), torch.float32, 10), _mk((N, K), torch.float32, 11)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(M, N, device="cuda")
+        Fn.gemm(0, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, drop=(0.25, 1234, 77))
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    ref = A @ B.t()
+    kept = outs[0] != 0
+    frac = 1.0 - float(kept.float().mean())
+    assert abs(frac - 0.25) < 0.01
+    assert torch.allclose(outs[0][kept], ref[kept] / 0.75, atol=1e-4, rtol=1e-5)
+    # the stand-alone dropout kernel regenerates the same mask from (seed, offset)
+    y = Fn._dropout_apply(ref.contiguous(), 0.25, 1234, 77)
+    assert torch.equal(y != 0, kept)

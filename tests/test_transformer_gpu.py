@@ -1,0 +1,237 @@
+"""GPU parity of the transformer path (HIP kernels through the C ABI) against the golden vectors generated from the
+reference modules: forward outputs, returned attention maps, and input/parameter gradients.
+
+float32 mode is the parity mode (exact-f32 matrix cores): tolerances 2e-4 abs on activations, 1e-3 rel on gradients.
+bfloat16 mode (training) is checked against the same fixtures with bf16-rounding tolerances."""
+import pytest
+import torch
+
+from conftest import sub
+from oracle import cpu_ref as R
+from speechain_amd import functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+F32 = dict(atol=2e-4, rtol=1e-3)
+BF16 = dict(atol=6e-2, rtol=6e-2)
+
+
+@pytest.fixture(params=[torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def mode(request):
+    Fn.set_compute_dtype(request.param)
+    yield request.param
+    Fn.set_compute_dtype(None)
+
+
+def tol(mode):
+    return F32 if mode == torch.float32 else BF16
+
+
+def close(a, b, t, what=""):
+    a = a.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = float((a - b).abs().max())
+    assert torch.allclose(a, b, **t), (what, err)
+
+
+def _w(x):
+    return torch.linspace(-1, 1, x.numel(), device=x.device).reshape(x.shape)
+
+
+def _load(mod, sd):
+    missing, unexpected = mod.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("posenc.posenc") or k.endswith("posenc") for k in missing), missing
+    return mod.cuda().eval()
+
+
+def test_posenc(golden, mode):
+    from speechain_amd.module.transformer.pos_enc import PositionalEncoding
+
+    g = golden("g3_posenc")
+    for typ in ("mix", "sep"):
+        pe = PositionalEncoding(posenc_type=typ, d_model=64, max_len=300)
+        assert torch.equal(pe.posenc[0, [0, 1, 2, 17, 150, 299]], g[f"{typ}_rows"])
+    pe = _load(PositionalEncoding(d_model=64, emb_scale=True, emb_layernorm=True, posenc_scale=True, max_len=300), sub(g, "full_sd."))
+    close(pe(g["x"].cuda()), g["full_out"], tol(mode) if mode == torch.float32 else dict(atol=0.15, rtol=3e-2), "posenc full")
+    pe2 = PositionalEncoding(d_model=64, max_len=300).cuda().eval()
+    close(pe2(g["x"].cuda()), g["plain_out"], tol(mode), "posenc plain")
+
+
+def test_mha(golden, mode):
+    from speechain_amd.module.transformer.attention import MultiHeadedAttention
+
+    g = golden("g4_layers")
+    t = tol(mode)
+    for tag, by_head in (("mha_dmodel", False), ("mha_byhead", True)):
+        m = _load(MultiHeadedAttention(num_heads=4, d_model=64, dropout=0.0, scale_dp_by_head=by_head), sub(g, f"{tag}.sd."))
+        q, kv = g[f"{tag}.q"].cuda().requires_grad_(), g[f"{tag}.kv"].cuda().requires_grad_()
+        y, p = m(kv, kv, q, g[f"{tag}.mask"].cuda())
+        close(y, g[f"{tag}.out"], t, tag + " out")
+        close(p, g[f"{tag}.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0), tag + " probs")
+        gq, gkv, gw = torch.autograd.grad((y.float() * _w(y)).sum(), [q, kv, m.q_layer.weight])
+        close(gq, g[f"{tag}.gq"], t, tag + " gq")
+        close(gkv, g[f"{tag}.gkv"], t, tag + " gkv")
+        close(gw, g[f"{tag}.gw_q"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else dict(atol=0.3, rtol=6e-2), tag + " gw")
+    # dh = 192, dense (B, T, T) causal & padding mask given explicitly
+    m = _load(MultiHeadedAttention(num_heads=2, d_model=384, dropout=0.0), sub(g, "mha192.sd."))
+    x = g["mha192.x"].cuda().requires_grad_()
+    y, p = m(x, x, x, g["mha192.mask"].cuda())
+    close(y, g["mha192.out"], t, "mha192 out")
+    close(p, g["mha192.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0), "mha192 probs")
+    (gx,) = torch.autograd.grad((y.float() * _w(y)).sum(), [x])
+    close(gx, g["mha192.gx"], t if mode == torch.float32 else dict(atol=0.2, rtol=6e-2), "mha192 gx")
+    # same result when the causal structure is given as a flag + (B,1,T) padding mask (what the decoder stack does)
+    pad = g["mha192.mask"][:, -1:, :].cuda()
+    y2, p2 = m(x, x, x, pad, _causal=True)
+    close(y2, g["mha192.out"], t, "mha192 causal-flag out")
+
+
+@pytest.mark.parametrize("tag,act,typ", [("ffn_relu", "ReLU", "linear"), ("ffn_gelu", "GELU", "linear"), ("ffn_conv", "ReLU", "conv")])
+def test_ffn(golden, mode, tag, act, typ):
+    from speechain_amd.module.transformer.feed_forward import PositionwiseFeedForward
+
+    g = golden("g4_layers")
+    f = _load(PositionwiseFeedForward(d_model=64, fdfwd_dim=160, dropout=0.0, fdfwd_activation=act, fdfwd_type=typ), sub(g, f"{tag}.sd."))
+    x = g[f"{tag}.x"].cuda().requires_grad_()
+    y = f(x)
+    t = tol(mode)
+    close(y, g[f"{tag}.out"], t, tag)
+    w = f.in_layer.weight if typ == "linear" else f.in_layer.conv_lyr.weight
+    gx, gw = torch.autograd.grad((y.float() * _w(y)).sum(), [x, w])
+    close(gx, g[f"{tag}.gx"], t, tag + " gx")
+    close(gw, g[f"{tag}.gw_in"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else dict(atol=0.3, rtol=6e-2), tag + " gw")
+
+
+def test_encoder_decoder_layers(golden, mode):
+    from speechain_amd.module.transformer.decoder import TransformerDecoderLayer
+    from speechain_amd.module.transformer.encoder import TransformerEncoderLayer
+
+    g = golden("g4_layers")
+    t = tol(mode) if mode == torch.float32 else dict(atol=0.12, rtol=6e-2)
+    tg = dict(atol=2e-3, rtol=2e-3) if mode == torch.float32 else dict(atol=0.5, rtol=0.1)
+    for tag, first in (("enc_pre", True), ("enc_post", False)):
+        e = _load(TransformerEncoderLayer(d_model=64, num_heads=4, fdfwd_dim=128, att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0,
+                                          fdfwd_activation="GELU", layernorm_first=first), sub(g, f"{tag}.sd."))
+        x = g[f"{tag}.x"].cuda().requires_grad_()
+        y, p = e(x, g[f"{tag}.mask"].cuda())
+        close(y, g[f"{tag}.out"], t, tag)
+        gx, gln, gb = torch.autograd.grad((y.float() * _w(y)).sum(), [x, e.att_layernorm.weight, e.multihead_att.output_layer.bias])
+        close(gx, g[f"{tag}.gx"], tg, tag + " gx")
+        close(gln, g[f"{tag}.g_attln_w"], tg, tag + " gln")
+        close(gb, g[f"{tag}.g_outb"], tg, tag + " gb")
+    d = _load(TransformerDecoderLayer(d_model=64, num_heads=4, fdfwd_dim=128, att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0,
+                                      fdfwd_activation="GELU", scale_dp_by_head=True), sub(g, "dec.sd."))
+    tgt, src = g["dec.tgt"].cuda().requires_grad_(), g["dec.src"].cuda().requires_grad_()
+    y, sp, ep = d(tgt, src, g["dec.tmask"].cuda(), g["dec.smask"].cuda())
+    close(y, g["dec.out"], t, "dec layer")
+    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0)
+    close(sp, g["dec.self_probs"], pt, "dec self probs")
+    close(ep, g["dec.encdec_probs"], pt, "dec encdec probs")
+    gt, gs = torch.autograd.grad((y.float() * _w(y)).sum(), [tgt, src])
+    close(gt, g["dec.gtgt"], tg, "dec gtgt")
+    close(gs, g["dec.gsrc"], tg, "dec gsrc")
+
+
+def test_stacks(golden, mode):
+    from speechain_amd.module.transformer.decoder import TransformerDecoder
+    from speechain_amd.module.transformer.encoder import TransformerEncoder
+
+    g = golden("g5_stacks")
+    t = tol(mode) if mode == torch.float32 else dict(atol=0.15, rtol=6e-2)
+    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=3e-2, rtol=0)
+    enc = _load(TransformerEncoder(d_model=64, num_heads=4, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                                   fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", posenc_maxlen=200), sub(g, "enc.sd."))
+    y, m, att, hid = enc(g["enc.x"].cuda(), g["enc.mask"].cuda())
+    close(y, g["enc.out"], t, "enc out")
+    assert torch.equal(m.cpu(), g["enc.mask"])
+    close(att[0], g["enc.att0"], pt, "att0")
+    close(att[1], g["enc.att1"], pt, "att1")
+    close(hid[0], g["enc.hid0"], t, "hid0")
+    close(hid[1], g["enc.hid1"], t, "hid1")
+    enc2 = _load(TransformerEncoder(d_model=48, num_heads=2, num_layers=2, fdfwd_dim=96, fdfwd_type="conv", posenc_dropout=0.0,
+                                    att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0, posenc_scale=True, emb_layernorm=True,
+                                    scale_dp_by_head=True, uni_direction=True, layernorm_first=False, posenc_maxlen=200), sub(g, "enc2.sd."))
+    y2, m2, att2, _ = enc2(g["enc2.x"].cuda(), g["enc2.mask"].cuda())
+    close(y2, g["enc2.out"], t, "enc2 out")
+    assert torch.equal(m2.cpu(), g["enc2.mask_out"])
+    close(att2[1], g["enc2.att1"], pt, "enc2 att1")
+    dec = _load(TransformerDecoder(d_model=64, num_heads=4, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
+                                   fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", emb_scale=False, posenc_maxlen=200),
+                sub(g, "dec.sd."))
+    yd, sa, ea, hd = dec(g["dec.tgt"].cuda(), g["enc.out"].cuda(), g["dec.tmask"].cuda(), g["enc.mask"].cuda())
+    close(yd, g["dec.out"], t, "dec out")
+    close(sa[1], g["dec.self_att1"], pt, "dec self att")
+    close(ea[1], g["dec.encdec_att1"], pt, "dec encdec att")
+    close(hd[0], g["dec.hid0"], t, "dec hid0")
+
+
+def test_losses(golden, mode):
+    from speechain_amd.criterion.cross_entropy import CrossEntropy
+    from speechain_amd.criterion.ctc import CTCLoss
+
+    g = golden("g6_losses")
+    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(atol=5e-2, rtol=2e-2)
+    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(atol=3e-3, rtol=5e-2)
+    for tag, conf in (("ce0", dict()), ("ce02", dict(label_smoothing=0.2)), ("ce02n", dict(label_smoothing=0.2, length_normalized=True))):
+        lg = g["ce_logits"].to(mode).cuda().requires_grad_()
+        loss = CrossEntropy(**conf)(logits=lg, text=g["text"].cuda(), text_len=g["text_len"].cuda())
+        close(loss, g[f"{tag}.loss"], lt, tag)
+        close(torch.autograd.grad(loss, lg)[0], g[f"{tag}.grad"], gt, tag + " grad")
+    lg = g["ctc_logits"].to(mode).cuda().requires_grad_()
+    loss = CTCLoss()(lg, g["enc_len"].cuda(), g["ctc_text"].cuda(), g["text_len"].cuda())
+    close(loss, g["ctc_loss"], lt, "ctc")
+    close(torch.autograd.grad(loss, lg)[0], g["ctc_grad"], gt, "ctc grad")
+
+
+def test_ctc_full_size_vs_oracle():
+    """BASELINE shapes: (32, 249, 5000) logits, 62 labels incl. repeats; value and gradient vs torch's CPU CTC."""
+    from speechain_amd.criterion.ctc import CTCLoss
+
+    gen = torch.Generator().manual_seed(3)
+    B, T, V, L = 32, 249, 5000, 64
+    logits = torch.randn(B, T, V, generator=gen)
+    text = torch.randint(1, V - 2, (B, L), generator=gen)
+    text[:, 10] = text[:, 9]  # a repeated label
+    text_len = torch.randint(20, L + 1, (B,), generator=gen)
+    text_len[0] = L
+    enc_len = torch.randint(150, T + 1, (B,), generator=gen)
+    enc_len[0] = T
+    for i in range(B):
+        text[i, 0] = V - 1
+        text[i, text_len[i] - 1] = V - 1
+        text[i, text_len[i]:] = 0
+    lg_ref = logits.clone().requires_grad_()
+    ref = R.ctc_loss(lg_ref, enc_len, text, text_len)
+    gref = torch.autograd.grad(ref, lg_ref)[0]
+    lg = logits.cuda().requires_grad_()
+    loss = CTCLoss()(lg, enc_len.cuda(), text.cuda(), text_len.cuda())
+    assert abs(float(loss) - float(ref)) < 1e-3 * abs(float(ref))
+    g = torch.autograd.grad(loss, lg)[0].cpu()
+    assert float((g - gref).abs().max()) < 1e-6 + 1e-3 * float(gref.abs().max())
+
+
+def test_harness_step(golden, mode):
+    """a-harness: encoder -> decoder -> heads -> 0.7 CE + 0.3 CTC with the reference's sequencing, values and gradients."""
+    from speechain_amd.harness import ASRTransformer
+
+    g = golden("g7_harness")
+    model = ASRTransformer(d_model=64, num_heads=4, enc_layers=2, dec_layers=2, fdfwd_dim=128, vocab_size=53, dropout=0.0,
+                           posenc_maxlen=200, label_smoothing=0.2, ctc_weight=0.3)
+    sd = sub(g, "sd.")
+    sd["embed.embed.weight"] = sd.pop("embed.weight")
+    _load(model, sd)
+    out = model(g["feat"].cuda(), g["feat_len"].cuda(), g["text"].cuda(), g["text_len"].cuda())
+    t = tol(mode) if mode == torch.float32 else dict(atol=0.2, rtol=6e-2)
+    close(out["enc"], g["enc"], t, "enc")
+    close(out["logits"], g["logits"], t, "logits")
+    close(out["ctc_logits"], g["ctc_logits"], t, "ctc_logits")
+    lt = dict(atol=2e-4, rtol=2e-4) if mode == torch.float32 else dict(atol=0.1, rtol=2e-2)
+    for k in ("ce", "ctc", "loss"):
+        close(out[k], g[k], lt, k)
+    out["loss"].backward()
+    gt = dict(atol=2e-4, rtol=2e-3) if mode == torch.float32 else dict(atol=5e-2, rtol=0.1)
+    close(model.encoder.trfm_layers[0].multihead_att.q_layer.weight.grad, g["g_enc0_q"], gt, "g enc0 q")
+    close(model.embed.embed.weight.grad, g["g_embed"], gt, "g embed")
+    close(model.decoder.trfm_layers[1].encdec_att.k_layer.bias.grad, g["g_dec1_encdec_kb"], gt, "g kb")
+    close(model.ctc_layer.linear.weight.grad, g["g_ctc_w"], gt, "g ctc w")
