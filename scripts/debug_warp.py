@@ -19,3 +19,7 @@ for (c, p, tmin) in [(306, 310, 619), (448, 447, 619), (500, 503, 1001)]:
     else:
         scale = torch.tensor((tmin - c - 1) / (tmin - p - 1), dtype=torch.float32); dst = t - p
     print("   scale", float(scale), "real", float(scale * dst), "rows with err:", torch.nonzero(err > 1e-5).flatten()[:10].tolist())
+
+    # torch-explicit evaluated with the oracle formula (CPU) for comparison
+    ref2 = R.specaug_apply(feat, torch.tensor([1001, tmin]), d, explicit_warp=True)
+    print("   kernel-vs-explicit", float((out - ref2).abs().max()), " interp-vs-explicit", float((ref - ref2).abs().max()))

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
     float scale;
     if (t < p.warp_pos) { base = 0; in_len = p.warp_center; dst = t; scale = p.scale_l; }
     else { base = p.warp_center; in_len = p.tmin - p.warp_center; dst = t - p.warp_pos; scale = p.scale_r; }
-    const float real = __fmul_rn(scale, (float)dst);  // no FMA contraction: aten rounds the product first
+    float real = scale * (float)dst;
+    asm volatile("" : "+v"(real));  // aten rounds the product before taking floor / fraction: keep hipcc from
+                                    // contracting it into fma(scale, dst, -floor) (HIP's __fmul_rn does not)
     int i0 = (int)floorf(real);
     if (i0 > in_len - 1) i0 = in_len - 1;
     float lam = real - (float)i0;
@@ -133,8 +135,8 @@ SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int 
     SC_CHECK_ARG(warp_pos >= 1 && warp_pos < tmin && warp_center >= 1 && warp_center < tmin && tmin <= T,
                  "sc_specaug_fwd: bad warp (center=%d pos=%d tmin=%d T=%d)", warp_center, warp_pos, tmin, T);
     const int lo = warp_pos, ro = tmin - warp_pos;
-    a.scale_l = lo > 1 ? (float)(warp_center - 1) / (float)(lo - 1) : 0.f;
-    a.scale_r = ro > 1 ? (float)(tmin - warp_center - 1) / (float)(ro - 1) : 0.f;
+    a.scale_l = lo > 1 ? (float)((double)(warp_center - 1) / (double)(lo - 1)) : 0.f;
+    a.scale_r = ro > 1 ? (float)((double)(tmin - warp_center - 1) / (double)(ro - 1)) : 0.f;
   }
   a.freq_len = freq_len; a.freq_pos = freq_pos; a.nf = nf;
   a.time_len = time_len; a.time_pos = time_pos; a.nt = nt;
