@@ -32,9 +32,9 @@ BATCH, SAMPLES = 32, 160000
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="frontend", choices=["frontend"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -79,6 +79,133 @@ class FrontendWorkload:
 
     def dominant_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.ev) / max(1, len(self.ev))
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak of MI355X (MI355X_MICROARCH.md)
+ASR_MODEL = dict(d_model=512, num_heads=8, enc_layers=12, dec_layers=6, fdfwd_dim=2048, vocab_size=5000, dropout=0.1,
+                 activation="GELU", label_smoothing=0.2, ctc_weight=0.3)
+TEXT_LEN = 64
+
+
+def synth_text(seed: int, device, vocab: int = 5000):
+    g = torch.Generator().manual_seed(1000 + seed)
+    text = torch.randint(1, vocab - 2, (BATCH, TEXT_LEN), generator=g)
+    text[:, 0] = vocab - 1
+    text[:, -1] = vocab - 1
+    return text.to(device), torch.full((BATCH,), TEXT_LEN, dtype=torch.int64, device=device)
+
+
+class ASRTrainStepWorkload:
+    """BASELINE.json configs[2] driven from waveforms: frontend -> SpecAugment -> conv2d prenet [64,64] (torch, outside the named
+    path) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip -> Adam (Noam), bf16 compute."""
+
+    name = ("ASR transformer-base train step (12enc/6dec d512 h8 ffn2048 V5000, bf16) from 32x10s@16kHz waveforms: frontend + "
+            "specaug + conv2d-prenet[64,64] + encoder + decoder + 0.7CE/0.3CTC + backward + clip + Adam (BASELINE configs[2])")
+    dtype = "bf16"
+    dominant = "gemm_bf16_kernel (all layouts)"
+
+    def __init__(self, device, seed, world):
+        from speechain_amd import functional as Fn
+        from speechain_amd.ddp import GradBucketReducer
+        from speechain_amd.harness import ASRTransformer, Conv2dSubsample
+        from speechain_amd.module.augment.specaug import SpecAugment
+        from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
+
+        Fn.set_compute_dtype(torch.bfloat16)
+        torch.manual_seed(0)  # identical initial weights on every rank
+        self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
+        self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
+        self.prenet = Conv2dSubsample(80, (64, 64), 512).to(device).train()
+        self.model = ASRTransformer(**ASR_MODEL).to(device).train()
+        for m in (self.prenet, self.model):
+            for p in m.parameters():
+                if p.dim() > 1:
+                    torch.nn.init.xavier_normal_(p)
+        self.params = [p for m in (self.prenet, self.model) for p in m.parameters()]
+        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0)
+        self.reducer.broadcast_parameters()
+        try:
+            self.opt = torch.optim.Adam(self.params, lr=2e-3, betas=(0.9, 0.98), eps=1e-9, fused=True)
+        except Exception:
+            self.opt = torch.optim.Adam(self.params, lr=2e-3, betas=(0.9, 0.98), eps=1e-9, foreach=True)
+        torch.manual_seed(1234 + seed)
+        self.wave, self.lens, _ = synth_batch(seed, device)
+        self.text, self.text_len = synth_text(seed, device)
+        self.nstep = 0
+        self.ev, self.flops = [], 0.0
+        self.world = world
+
+    def step(self, timed: bool):
+        from speechain_amd._lib import lib
+
+        self.nstep += 1
+        sample = timed and (self.nstep % 4 == 0)  # HIP events around every GEMM launch on one timed step in four
+        lib.timing = {"sc_gemm": self.ev} if sample else None
+        lib.flop_log = [] if sample else None
+        for g in self.opt.param_groups:  # Noam schedule, warmup 25000 (optim_sche/noam.py:42-59)
+            g["lr"] = 2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5
+        self.reducer.zero_grad()
+        with torch.no_grad():
+            feat, flen = self.fe(self.wave, self.lens)
+            feat, flen = self.sa(feat, flen)
+        x, xlen = self.prenet(feat, flen)
+        out = self.model(x, xlen, self.text, self.text_len)
+        out["loss"].backward()
+        self.reducer.wait()
+        flats = [b["flat"] for b in self.reducer.buckets]
+        norm = torch.sqrt(sum((f * f).sum() for f in flats))
+        coef = torch.clamp(5.0 / (norm + 1e-6), max=1.0)
+        for f in flats:
+            f.mul_(coef)
+        self.opt.step()
+        if sample:
+            self.flops += sum(lib.flop_log)
+        lib.timing = None
+        lib.flop_log = None
+        return out["loss"]
+
+    def roofline(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.ev)
+        n = len(self.ev)
+        achieved = self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "mfma", "kernel": self.dominant, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                "launches_timed": n, "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops,
+                "note": "sum of 2*M*N*K*batch over the sampled sc_gemm launches / sum of their HIP-event durations"}
+
+
+def cpu_baseline_train(seconds: float):
+    """The oracle's ASR step (frontend -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
+    on a bounded sample: ONE step over 2 of the 32 utterances (same per-utterance shapes), scaled to utterances/s."""
+    from oracle import cpu_ref as R
+    from speechain_amd.harness import ASRTransformer, Conv2dSubsample
+
+    cores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", 16)))
+    torch.set_num_threads(cores)
+    nb = 2
+    torch.manual_seed(0)
+    prenet = Conv2dSubsample(80, (64, 64), 512)
+    model = ASRTransformer(**ASR_MODEL)
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("posenc")) for k, v in model.state_dict().items()}
+    P["embed.weight"] = P.pop("embed.embed.weight")
+    cfg = dict(enc_layers=12, dec_layers=6, num_heads=8, d_model=512, activation="GELU", label_smoothing=0.2, ctc_weight=0.3)
+    wave, _, lens = synth_batch(0, "cpu")
+    text, text_len = synth_text(0, "cpu")
+    wave, lens, text, text_len = wave[:nb].squeeze(-1), lens[:nb], text[:nb], text_len[:nb]
+
+    def one():
+        feat, flen = R.speech2mel(wave, lens, **ASR_FRONTEND)
+        d = R.specaug_draw(flen, nb, 80, **SPECAUG)
+        feat = R.specaug_apply(feat, flen, d)
+        x, xlen = prenet(feat, flen)
+        out = R.asr_forward_loss(x, xlen, text, text_len, P, cfg)
+        out["loss"].backward()
+
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return dict(value=round(nb / dt, 4), unit="utterances/s", cores=cores, kind="port",
+                sample=f"1 train step (fwd+bwd, no optimizer) over {nb} of the 32 utterances, torch-CPU oracle, fp32, {cores} threads, {dt:.1f} s")
 
 
 def cpu_baseline(seconds: float):
@@ -126,7 +253,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     torch.manual_seed(1234 + rank)
-    wl = FrontendWorkload(device, seed=rank)
+    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world)
     for _ in range(args.warmup):
         wl.step(False)
 
@@ -148,8 +275,14 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        kms = wl.dominant_ms()
-        achieved = wl.alg_bytes / (kms * 1e-3) / 1e9
+        if args.workload == "frontend":
+            kms = wl.dominant_ms()
+            achieved = wl.alg_bytes / (kms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes}
+        else:
+            roof = wl.roofline()
         line = {
             "metric": "utterances/sec (10 s@16 kHz, bsz32)",
             "value": round(BATCH * args.steps * world / elapsed, 2),
@@ -164,13 +297,12 @@ def main():
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": SAMPLES,
-                       "sharding": f"{world} independent per-GPU batches, no collective"},
-            "roofline": {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes},
+                       "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
+                                    f"dp{world}: per-GPU batch 32, bucketed RCCL gradient all-reduce overlapped with backward")},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

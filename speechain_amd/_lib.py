@@ -50,6 +50,7 @@ class _Lib:
         # optional per-entry-point HIP-event timing (bench.py): {symbol: [(start, stop), ...]} recorded on the
         # current stream tightly around the launch; None = off (the default, zero overhead)
         self.timing = None
+        self.flop_log = None  # optional list receiving 2*M*N*K*batch of every sc_gemm call (bench.py roofline)
 
     def load(self):
         if self._dll is not None:
@@ -71,6 +72,8 @@ class _Lib:
     def call(self, name: str, *args):
         """Calls an int-status entry point; raises RuntimeError(sc_last_error()) on a non-zero status."""
         dll = self.load()
+        if self.flop_log is not None and name == "sc_gemm":
+            self.flop_log.append(2.0 * args[6] * args[7] * args[8] * args[12] * args[13])
         rec = self.timing.get(name) if self.timing is not None else None
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

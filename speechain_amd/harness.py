@@ -29,6 +29,29 @@ class Embed(torch.nn.Module):
         return self.embed(text)
 
 
+class Conv2dSubsample(torch.nn.Module):
+    """Stand-in for the recipe's Conv2dPrenet (module/prenet/conv2d.py:164-280: two Conv2d(k3, s2) + BatchNorm2d + LeakyReLU,
+    then Linear) -- OUTSIDE the named hot path, so it is plain torch/MIOpen here.  (B, T, F) -> (B, T', d)."""
+
+    def __init__(self, feat_dim: int = 80, conv_dims=(64, 64), d_model: int = 512):
+        super().__init__()
+        layers, prev, f = [], 1, feat_dim
+        for c in conv_dims:
+            layers += [torch.nn.Conv2d(prev, c, 3, 2, bias=False), torch.nn.BatchNorm2d(c), torch.nn.LeakyReLU()]
+            prev, f = c, (f - 3) // 2 + 1
+        self.conv = torch.nn.Sequential(*layers)
+        self.linear = torch.nn.Linear(prev * f, d_model)
+        self.n_conv = len(conv_dims)
+
+    def forward(self, feat, feat_len):
+        x = self.conv(feat.unsqueeze(1))
+        B, C, T, Fd = x.shape
+        x = x.transpose(1, 2).contiguous().view(B, T, C * Fd)
+        for _ in range(self.n_conv):
+            feat_len = torch.div(feat_len - 3, 2, rounding_mode="floor") + 1
+        return self.linear(x), feat_len
+
+
 class ASRTransformer(torch.nn.Module):
     def __init__(self, d_model=512, num_heads=8, enc_layers=12, dec_layers=6, fdfwd_dim=2048, vocab_size=5000, dropout=0.1,
                  activation="GELU", posenc_maxlen=5000, label_smoothing=0.2, ctc_weight=0.3):
