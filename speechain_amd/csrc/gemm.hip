@@ -46,6 +46,8 @@ struct GemmArgs {
   int accumulate;
   int a_vec, b_vec;  // 16-byte vector loads allowed for A / B
   int c_vec, c_vec32;  // vector accesses allowed for C/aux/pre_out in the compute dtype / for an f32 C
+  int splitk;          // > 1: blockIdx.z is a K slice of ksplit_len, raw f32 partial tiles go to slab z of C
+  int ksplit_len;
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -222,9 +224,30 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 // One operand tile (128 rows x 32 k) global -> registers.  Non-transposed: chunk = 8 consecutive k of one row.
 // Transposed: chunk = 8 consecutive rows of one k.
+constexpr int LDT16 = 160;  // transposed-operand tile: 32 k-rows x 128 columns, rows padded to 160 elements (320 B) so the
+                            // 32 lanes of a ds_read_b64_tr_b16 half-wave cover all 64 LDS banks exactly once
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// One operand tile global -> registers.  Non-transposed (k contiguous in memory): tile = 128 rows x 32 k, chunk = 8
+// consecutive k of one row.  Transposed (row index contiguous): tile = 32 k-rows x 128 rows, chunk = 8 consecutive rows of
+// one k -- still a coalesced 16-byte load; the transposition happens in the LDS *read* (ds_read_b64_tr_b16).
 template <bool TR>
 __device__ __forceinline__ void load_tile16(const unsigned short* base, long long ld, int rows, int K, int row0, int k0,
                                             bool vec, int tid, uint4 (&reg)[2]) {
+  // wave-uniform fast path: interior tile, 16-byte aligned -> two unconditional 16-byte loads per lane (keeps the
+  // compiler's vmcnt bookkeeping counted, so three tiles really stay in flight)
+  const bool full = vec && (row0 + BM <= rows) && (k0 + BK16 <= K);
+  if (full) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const unsigned short* src = !TR ? base + (long long)(row0 + (c >> 2)) * ld + k0 + (c & 3) * 8
+                                      : base + (long long)(k0 + (c >> 4)) * ld + row0 + (c & 15) * 8;
+      reg[i] = *(const uint4*)src;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = tid + 256 * i;
@@ -236,8 +259,8 @@ __device__ __forceinline__ void load_tile16(const unsigned short* base, long lon
       nvalid = (r < rows) ? min(8, K - k) : 0;
       src = base + (long long)r * ld + k;
     } else {
-      k = k0 + (c & 31);
-      r = row0 + (c >> 5) * 8;
+      k = k0 + (c >> 4);
+      r = row0 + (c & 15) * 8;
       nvalid = (k < K) ? min(8, rows - r) : 0;
       src = base + (long long)k * ld + r;
     }
@@ -260,17 +283,27 @@ __device__ __forceinline__ void store_tile16(unsigned short* lds, int tid, const
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = tid + 256 * i;
-    if (!TR) {
-      *(uint4*)(lds + (c >> 2) * LD16 + (c & 3) * 8) = reg[i];
-    } else {
-      const int k = c & 31, r = (c >> 5) * 8;
-      const unsigned w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lds[(r + 2 * j) * LD16 + k] = (unsigned short)(w[j] & 0xFFFF);
-        lds[(r + 2 * j + 1) * LD16 + k] = (unsigned short)(w[j] >> 16);
-      }
-    }
+    if (!TR) *(uint4*)(lds + (c >> 2) * LD16 + (c & 3) * 8) = reg[i];
+    else *(uint4*)(lds + (c >> 4) * LDT16 + (c & 15) * 8) = reg[i];
+  }
+}
+
+// MFMA 32x32x16 operand fragment of lane l: 8 consecutive k (k = ks*16 + 8*(l>>5) + j) of tile row `rbase + (l & 31)`.
+template <bool TR>
+__device__ __forceinline__ bf16x8_t read_frag16(const unsigned short* tile, int rbase, int ks, int lane) {
+  if (!TR) {
+    return *(const bf16x8_t*)(tile + (rbase + (lane & 31)) * LD16 + ks * 16 + (lane >> 5) * 8);
+  } else {
+    // hardware-transposing LDS read: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies the address of
+    // k-row q, columns 4p..4p+3 and receives column (lane & 15) of the four k-rows.
+    const int g = lane >> 4, ip = lane & 15, q = ip >> 2, pp = ip & 3;
+    const unsigned short* a = tile + (ks * 16 + 8 * (g >> 1) + q) * LDT16 + rbase + 16 * (g & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * LDT16));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
   }
 }
 
@@ -297,42 +330,133 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[2], rb[2];
-  const int nk = (p.K + BK16 - 1) / BK16;
-  load_tile16<TA>(A, p.lda, p.M, p.K, m0, 0, p.a_vec, tid, ra);
-  load_tile16<TB>(B, p.ldb, p.N, p.K, n0, 0, p.b_vec, tid, rb);
-  store_tile16<TA>(As, tid, ra);
-  store_tile16<TB>(Bs, tid, rb);
-  __syncthreads();
+  // K range of this workgroup (split-K: slice z of the contraction)
+  const int kbeg = p.splitk > 1 ? z * p.ksplit_len : 0;
+  const int kend = p.splitk > 1 ? min(p.K, kbeg + p.ksplit_len) : p.K;
+  const int nk = (kend - kbeg + BK16 - 1) / BK16;
 
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nk) {
-      load_tile16<TA>(A, p.lda, p.M, p.K, m0, (t + 1) * BK16, p.a_vec, tid, ra);
-      load_tile16<TB>(B, p.ldb, p.N, p.K, n0, (t + 1) * BK16, p.b_vec, tid, rb);
+  // 3-deep register prefetch ring (tiles t+1..t+3 in flight while tile t is multiplied) over double-buffered LDS:
+  // the K loop is latency-bound at these problem sizes (~250 workgroups, 16-64 K tiles), not bandwidth-bound.
+  uint4 ra0[2], rb0[2], ra1[2], rb1[2], ra2[2], rb2[2];
+#define SC_LOAD(RA, RB, T)                                                              \
+  do {                                                                                  \
+    if ((T) < nk) {                                                                     \
+      load_tile16<TA>(A, p.lda, p.M, kend, m0, kbeg + (T) * BK16, p.a_vec, tid, RA);    \
+      load_tile16<TB>(B, p.ldb, p.N, kend, n0, kbeg + (T) * BK16, p.b_vec, tid, RB);    \
+    }                                                                                   \
+  } while (0)
+#define SC_COMPUTE(CUR)                                                                                         \
+  do {                                                                                                          \
+    const unsigned short* as = As + (CUR) * BM * LD16;                                                          \
+    const unsigned short* bs = Bs + (CUR) * BM * LD16;                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+      bf16x8_t a[2], b[2];                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
+        a[i] = read_frag16<TA>(as, wr * 64 + i * 32, ks, lane);                                                 \
+        b[i] = read_frag16<TB>(bs, wc * 64 + i * 32, ks, lane);                                                 \
+      }                                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);                  \
+    }                                                                                                           \
+  } while (0)
+#define SC_STEP(T, RLOAD_A, RLOAD_B, RNEXT_A, RNEXT_B)                                  \
+  do {                                                                                  \
+    SC_LOAD(RLOAD_A, RLOAD_B, (T) + 3);                                                 \
+    SC_COMPUTE((T) & 1);                                                                \
+    if ((T) + 1 < nk) {                                                                 \
+      store_tile16<TA>(As + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_A);                 \
+      store_tile16<TB>(Bs + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_B);                 \
+    }                                                                                   \
+    __syncthreads();                                                                    \
+  } while (0)
+
+  // interior, aligned workgroups run a branch-free steady state (unconditional 16-byte loads -> the compiler keeps
+  // counted vmcnt waits, so two tiles stay in flight across every barrier); edges / tails take the guarded steps.
+  const bool fast = p.a_vec && p.b_vec && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+#define SC_LOAD_FAST(RA, RB, T)                                                                                   \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                            \
+      const int c_ = tid + 256 * i_;                                                                              \
+      const int kk_ = kbeg + (T) * BK16;                                                                          \
+      RA[i_] = *(const uint4*)(!TA ? A + (long long)(m0 + (c_ >> 2)) * p.lda + kk_ + (c_ & 3) * 8                 \
+                                   : A + (long long)(kk_ + (c_ >> 4)) * p.lda + m0 + (c_ & 15) * 8);              \
+      RB[i_] = *(const uint4*)(!TB ? B + (long long)(n0 + (c_ >> 2)) * p.ldb + kk_ + (c_ & 3) * 8                 \
+                                   : B + (long long)(kk_ + (c_ >> 4)) * p.ldb + n0 + (c_ & 15) * 8);              \
+    }                                                                                                             \
+  } while (0)
+#define SC_STEP_FAST(T, RLOAD_A, RLOAD_B, RNEXT_A, RNEXT_B)                             \
+  do {                                                                                  \
+    SC_LOAD_FAST(RLOAD_A, RLOAD_B, (T) + 3);                                            \
+    SC_COMPUTE((T) & 1);                                                                \
+    store_tile16<TA>(As + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_A);                   \
+    store_tile16<TB>(Bs + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_B);                   \
+    __syncthreads();                                                                    \
+  } while (0)
+
+  int t = 0;
+  const int nfull = (kend - kbeg) / BK16;  // tiles that lie completely inside [kbeg, kend)
+  if (fast && nfull >= 6) {
+    SC_LOAD_FAST(ra0, rb0, 0);
+    SC_LOAD_FAST(ra1, rb1, 1);
+    SC_LOAD_FAST(ra2, rb2, 2);
+    store_tile16<TA>(As, tid, ra0);
+    store_tile16<TB>(Bs, tid, rb0);
+    __syncthreads();
+    for (; t + 6 <= nfull; t += 3) {  // steps t, t+1, t+2 load tiles t+3, t+4, t+5 (all full)
+      SC_STEP_FAST(t, ra0, rb0, ra1, rb1);
+      SC_STEP_FAST(t + 1, ra1, rb1, ra2, rb2);
+      SC_STEP_FAST(t + 2, ra2, rb2, ra0, rb0);
     }
-    const unsigned short* as = As + cur * BM * LD16;
-    const unsigned short* bs = Bs + cur * BM * LD16;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *(const bf16x8_t*)(as + (wr * 64 + i * 32 + li) * LD16 + ks * 16 + h * 8);
-        b[i] = *(const bf16x8_t*)(bs + (wc * 64 + i * 32 + li) * LD16 + ks * 16 + h * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nk) {
-      store_tile16<TA>(As + (cur ^ 1) * BM * LD16, tid, ra);
-      store_tile16<TB>(Bs + (cur ^ 1) * BM * LD16, tid, rb);
+    // here: tile t is in LDS[t & 1], tiles t+1 / t+2 are in ring slots 1 / 2 (t is a multiple of 3)
+  } else {
+    SC_LOAD(ra0, rb0, 0);
+    SC_LOAD(ra1, rb1, 1);
+    SC_LOAD(ra2, rb2, 2);
+    if (nk > 0) {
+      store_tile16<TA>(As, tid, ra0);
+      store_tile16<TB>(Bs, tid, rb0);
     }
     __syncthreads();
   }
+  for (; t < nk; t += 3) {
+    SC_STEP(t, ra0, rb0, ra1, rb1);
+    if (t + 1 < nk) SC_STEP(t + 1, ra1, rb1, ra2, rb2);
+    if (t + 2 < nk) SC_STEP(t + 2, ra2, rb2, ra0, rb0);
+  }
+#undef SC_LOAD_FAST
+#undef SC_STEP_FAST
+#undef SC_LOAD
+#undef SC_COMPUTE
+#undef SC_STEP
 
+  if (p.splitk > 1) {  // raw partial tile -> slab z (f32, no epilogue); the reduce kernel finishes the job
+    float* stage = (float*)smem + wid * 32 * STG_LD;
+    float* slab = (float*)p.C + (long long)z * p.M * p.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * STG_LD + j * 32 + li] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      for (int it = 0; it < 8; ++it) {
+        const int q = lane + 64 * it;
+        const int row = q >> 4, c4 = (q & 15) * 4;
+        const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + c4;
+        if (m < p.M && n < p.N) {
+          const f32x4 v = *(const f32x4*)(stage + row * STG_LD + c4);
+          float* dst = slab + (long long)m * p.ldc + n;
+          if (n + 4 <= p.N && p.c_vec32) *(f32x4*)dst = v * p.alpha;
+          else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e] * p.alpha;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    return;
+  }
   epilogue_wave<unsigned short>(p, (float*)smem, acc, zoffC, z, m0, n0, wid, lane);
 }
 
@@ -453,6 +577,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
   epilogue_wave<float>(p, smem, acc, zoffC, z, m0, n0, wid, lane);
 }
 
+// out[i] (+)= sum_s slab[s][i]   (deterministic split-K second stage)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int S, long long n, float* out, int accumulate) {
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 s = *(const f32x4*)(slabs + i);
+      for (int k = 1; k < S; ++k) s += *(const f32x4*)(slabs + (long long)k * n + i);
+      if (accumulate) s += *(const f32x4*)(out + i);
+      *(f32x4*)(out + i) = s;
+    } else {
+      for (long long e = i; e < n; ++e) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slabs[(long long)k * n + e];
+        out[e] = accumulate ? out[e] + s : s;
+      }
+    }
+  }
+}
+
 template <typename K>
 int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const char* name) {
   dim3 grid(sc_cdiv(a.N, BN), sc_cdiv(a.M, BM), nbatch);
@@ -507,4 +650,41 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   if (!ta && tb) return launch(gemm_f32_kernel<false, true>, a, nb, stream, "gemm_f32<NN>");
   if (ta && !tb) return launch(gemm_f32_kernel<true, false>, a, nb, stream, "gemm_f32<TT>");
   return launch(gemm_f32_kernel<true, true>, a, nb, stream, "gemm_f32<TN>");
+}
+
+// Split-K product for wgrad-shaped problems (small M x N output, long contraction): C (f32, M x N, ldc == N)
+// (+)= alpha * opA opB^T with the contraction cut into `splitk` slices whose partial tiles go to `workspace`
+// (splitk * M * N floats) and are summed by a second, deterministic kernel.  bf16 operands only.
+SC_API long long sc_gemm_splitk_workspace(int M, int N, int splitk) { return (long long)splitk * M * N * (long long)sizeof(float); }
+
+SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M, int N, int K, long long lda, long long ldb,
+                          float alpha, int splitk, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(A && B && C && workspace, "sc_gemm_splitk: null pointer");
+  SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && splitk >= 2 && splitk <= 64, "sc_gemm_splitk: bad sizes");
+  SC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? N : K), "sc_gemm_splitk: leading dimension too small");
+  SC_CHECK_ARG(ws_bytes >= sc_gemm_splitk_workspace(M, N, splitk), "sc_gemm_splitk: workspace too small");
+  GemmArgs a{};
+  a.A = A; a.B = B; a.C = workspace; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N;
+  a.nb2 = splitk; a.alpha = alpha; a.out_f32 = 1;
+  a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * 2) % 16 == 0);
+  a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * 2) % 16 == 0);
+  a.c_vec32 = ((uintptr_t)workspace % 16 == 0) && (N % 4 == 0);
+  a.c_vec = a.c_vec32;
+  a.splitk = splitk;
+  a.ksplit_len = ((K + splitk - 1) / splitk + BK16 - 1) / BK16 * BK16;
+  const int slices = (K + a.ksplit_len - 1) / a.ksplit_len;
+  a.splitk = slices > 1 ? slices : 2;  // keep the split-K code path even if rounding left a single slice
+  int rc;
+  if (!ta && !tb) rc = launch(gemm_bf16_kernel<false, false>, a, slices, stream, "gemm_bf16<NT> split-K");
+  else if (!ta && tb) rc = launch(gemm_bf16_kernel<false, true>, a, slices, stream, "gemm_bf16<NN> split-K");
+  else if (ta && !tb) rc = launch(gemm_bf16_kernel<true, false>, a, slices, stream, "gemm_bf16<TT> split-K");
+  else rc = launch(gemm_bf16_kernel<true, true>, a, slices, stream, "gemm_bf16<TN> split-K");
+  if (rc != SC_OK) return rc;
+  const long long n = (long long)M * N;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, slices, n, C, accumulate);
+  SC_LAUNCH_CHECK("splitk_reduce_kernel");
+  return SC_OK;
 }

@@ -126,26 +126,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
   }
 }
 
-// out[j][k] = sum_p part[(p * nout + j) * D + k]   (deterministic second stage of column reductions)
+// out[j][k] = sum_p part[(p * nout + j) * D + k]   (deterministic second stage of column reductions).
+// grid (ceil(D/16), nout); 256 threads = 16 columns x 16 partial-lanes, combined through LDS.
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int P, int nout, int D, float* out0, float* out1) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= D) return;
-  for (int j = 0; j < nout; ++j) {
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[((long long)p * nout + j) * D + k];
-    (j == 0 ? out0 : out1)[k] = s;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
+  const int j = blockIdx.y;
+  float s = 0.f;
+  if (k < D)
+    for (int p = pl; p < P; p += 16) s += part[((long long)p * nout + j) * D + k];
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && k < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][c];
+    (j == 0 ? out0 : out1)[k] = t;
   }
 }
 
-// column sums of an (R, N) matrix with row stride ld: partial[blockIdx.y][n]
+// column sums of an (R, N) matrix with row stride ld: part[blockIdx.y][n]; 256 threads = 64 columns x 4 row-lanes
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* x, long long R, int N, long long ld, int rows_per_block, float* part) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
   float s = 0.f;
-  for (long long r = r0; r < r1; ++r) s += Row<T>::ld(x, r * ld + n);
-  part[(long long)blockIdx.y * N + n] = s;
+  if (n < N)
+    for (long long r = r0 + rl; r < r1; r += 4) s += Row<T>::ld(x, r * ld + n);
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && n < N) part[(long long)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 // ---- masked softmax ------------------------------------------------------------------------------------------------
@@ -355,8 +368,8 @@ SC_API int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const 
 }
 
 SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
-  long long blocks = (R + 31) / 32;
-  if (blocks > 512) blocks = 512;
+  long long blocks = (R + 7) / 8;
+  if (blocks > 1024) blocks = 1024;
   return blocks * 2 * D * (long long)sizeof(float);
 }
 
@@ -366,8 +379,8 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   SC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "sc_layernorm_bwd: null pointer");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
   SC_CHECK_ARG(ws_bytes >= sc_layernorm_bwd_workspace(R, D), "sc_layernorm_bwd: workspace too small");
-  long long blocks = (R + 31) / 32;
-  if (blocks > 512) blocks = 512;
+  long long blocks = (R + 7) / 8;
+  if (blocks > 1024) blocks = 1024;
   const int rpb = (int)((R + blocks - 1) / blocks);
   blocks = (R + rpb - 1) / rpb;
   const size_t smem = (size_t)8 * D * sizeof(float);
@@ -375,14 +388,14 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
                 (float*)workspace, R, D, rpb);
   SC_LAUNCH_CHECK("layernorm_bwd_kernel");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 256)), dim3(256), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(256), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
   SC_LAUNCH_CHECK("reduce_parts_kernel");
   return SC_OK;
 }
 
 SC_API long long sc_colsum_workspace(long long R, int N) {
-  long long strips = (R + 255) / 256;
-  if (strips > 256) strips = 256;
+  long long strips = (R + 63) / 64;
+  if (strips > 128) strips = 128;
   return strips * N * (long long)sizeof(float);
 }
 
@@ -391,13 +404,13 @@ SC_API int sc_colsum(int dtype, const void* x, long long R, int N, long long ld,
   SC_CHECK_ARG(x && out && workspace, "sc_colsum: null pointer");
   SC_CHECK_ARG(R >= 1 && N >= 1 && ld >= N, "sc_colsum: bad sizes");
   SC_CHECK_ARG(ws_bytes >= sc_colsum_workspace(R, N), "sc_colsum: workspace too small");
-  long long strips = (R + 255) / 256;
-  if (strips > 256) strips = 256;
+  long long strips = (R + 63) / 64;
+  if (strips > 128) strips = 128;
   const int rpb = (int)((R + strips - 1) / strips);
   strips = (R + rpb - 1) / rpb;
-  SC_DISPATCH_T(dtype, colsum_kernel, dim3(sc_cdiv(N, 256), (unsigned)strips), dim3(256), 0, stream, x, R, N, ld, rpb, (float*)workspace);
+  SC_DISPATCH_T(dtype, colsum_kernel, dim3(sc_cdiv(N, 64), (unsigned)strips), dim3(256), 0, stream, x, R, N, ld, rpb, (float*)workspace);
   SC_LAUNCH_CHECK("colsum_kernel");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(N, 256)), dim3(256), 0, stream, (const float*)workspace, (int)strips, 1, N, out, out);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(N, 16), 1), dim3(256), 0, stream, (const float*)workspace, (int)strips, 1, N, out, out);
   SC_LAUNCH_CHECK("reduce_parts_kernel");
   return SC_OK;
 }

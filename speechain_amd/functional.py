@@ -7,6 +7,7 @@ Stateless dropout: each dropout site draws (seed, offset) from :class:`DropoutSt
 identical keep-mask from the saved pair, so no mask tensor is stored.
 """
 import math
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -117,6 +118,8 @@ class _WeightCache:
         key = (tuple(id(p) for p in params), dtype)
         ver = tuple((p._version, p.data_ptr()) for p in params)
         hit = self.store.get(key) if cacheable else None
+        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
+            hit = None  # an id() was recycled by a different (newer) parameter object: the entry is stale
         if hit is not None and hit[0] == ver:
             return hit[1]
         K = params[0].size(1)
@@ -128,7 +131,9 @@ class _WeightCache:
             lib.call("sc_cast", F32, BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r * K), src.numel(), stream())
             r += p.size(0)
         if cacheable:
-            self.store[key] = (ver, buf)
+            if len(self.store) > 4096:  # entries of dead parameters (models created and dropped) are not worth keeping
+                self.store = {k: v for k, v in self.store.items() if all(r() is not None for r in v[2])}
+            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
 
     def vector(self, params: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
@@ -140,11 +145,11 @@ class _WeightCache:
         key = (tuple(id(p) for p in params), "vec")
         ver = tuple((p._version, p.data_ptr()) for p in params)
         hit = self.store.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
             return hit[1]
         buf = torch.cat([p.detach() for p in params])
         if all(p.is_leaf for p in params):
-            self.store[key] = (ver, buf)
+            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
 
 
@@ -162,6 +167,23 @@ def gemm(code: int, A, B, C, M: int, N: int, K: int, lda: int, ldb: int, ldc: in
     lib.call("sc_gemm", code, ta, tb, A, B, C, M, N, K, lda, ldb, ldc, nb[0], nb[1], sA[0], sA[1], sB[0], sB[1], sC[0], sC[1],
              float(alpha), _p(bias), act, pre_out, aux, ldaux, aux_mode, float(drop[0]), int(drop[1]), int(drop[2]),
              1 if out_f32 else 0, 1 if accumulate else 0, stream())
+
+
+def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K).  The output is small and the contraction long, so in bf16 mode the
+    contraction is split across workgroups (sc_gemm_splitk) to fill the chip."""
+    M, N = dz.shape
+    K = x2.size(1)
+    dW = torch.empty(N, K, dtype=torch.float32, device=dz.device)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    splitk = min(16, max(1, 512 // tiles), max(1, M // 256))
+    if code == BF16 and splitk >= 2:
+        ws = torch.empty(lib.value("sc_gemm_splitk_workspace", N, K, splitk), dtype=torch.uint8, device=dz.device)
+        lib.call("sc_gemm_splitk", 1, 1, _p(dz), _p(x2), _p(dW), N, K, M, dz.stride(0), x2.stride(0), 1.0, splitk, 0, _p(ws),
+                 ws.numel(), stream())
+    else:
+        gemm(code, _p(dz), _p(x2), _p(dW), N, K, M, dz.stride(0), x2.stride(0), K, ta=1, tb=1, out_f32=True)
+    return dW
 
 
 def _colsum(x2d: torch.Tensor) -> torch.Tensor:
@@ -228,8 +250,7 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             gemm(code, _p(dz), _p(W), _p(dx), M, K, N, N, K, K, tb=1)  # dx = dz W
             dx = dx.reshape(xshape)
-        dW = torch.empty(N, K, dtype=torch.float32, device=x2.device)
-        gemm(code, _p(dz), _p(x2), _p(dW), N, K, M, N, K, K, ta=1, tb=1, out_f32=True)  # dW = dz^T x
+        dW = wgrad(code, dz, x2)  # dW = dz^T x
         dws = list(dW.split(rows, dim=0))
         dbs = [None] * len(rows)
         if any(has_b):
@@ -283,8 +304,7 @@ class _LinearAct(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             gemm(code, _p(dpre), _p(W), _p(dx), M, K, N, N, K, K, tb=1)
             dx = dx.reshape(xshape)
-        dW = torch.empty(N, K, dtype=torch.float32, device=x2.device)
-        gemm(code, _p(dpre), _p(x2), _p(dW), N, K, M, N, K, K, ta=1, tb=1, out_f32=True)
+        dW = wgrad(code, dpre, x2)
         db = _colsum(dpre) if has_b else None
         return dx, dW, db, None, None
 
@@ -340,15 +360,13 @@ class _FFN(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dz = _dropout_apply(dy2, p_res, s2, o2)
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
-        dW2 = torch.empty(K, Fd, dtype=torch.float32, device=x2.device)
-        gemm(code, _p(dz), _p(h), _p(dW2), K, Fd, M, K, Fd, Fd, ta=1, tb=1, out_f32=True)
+        dW2 = wgrad(code, dz, h)
         db2 = _colsum(dz) if has_b2 else None
         # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
         dpre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
         gemm(code, _p(dz), _p(W2), _p(dpre), M, Fd, K, K, Fd, Fd, tb=1, act=act, aux=_p(h_pre), ldaux=Fd, aux_mode=2,
              drop=(p_h, s1, o1))
-        dW1 = torch.empty(Fd, K, dtype=torch.float32, device=x2.device)
-        gemm(code, _p(dpre), _p(x2), _p(dW1), Fd, K, M, Fd, K, K, ta=1, tb=1, out_f32=True)
+        dW1 = wgrad(code, dpre, x2)
         db1 = _colsum(dpre) if has_b1 else None
         dx = None
         if ctx.needs_input_grad[0]:

@@ -104,3 +104,15 @@ def test_dropout_epilogue_is_reproducible_and_unbiased():
     # the stand-alone dropout kernel regenerates the same mask from (seed, offset)
     y = Fn._dropout_apply(ref.contiguous(), 0.25, 1234, 77)
     assert torch.equal(y != 0, kept)
+
+
+@pytest.mark.parametrize("M,N,K", [(7968, 2048, 512), (2016, 512, 512), (999, 130, 70), (300, 5000, 512)])
+def test_wgrad_split_k(M, N, K):
+    """dW = dz^T x through the split-K path (bf16) and the plain path (f32) against fp64."""
+    for dtype in (torch.bfloat16, torch.float32):
+        dz, x = _mk((M, N), dtype, 20), _mk((M, K), dtype, 21)
+        dW = Fn.wgrad(Fn.dcode(dz), dz, x)
+        ref = dz.double().t() @ x.double()
+        assert dW.dtype == torch.float32 and dW.shape == (N, K)
+        tol = dict(atol=2e-3 * math.sqrt(M / 64), rtol=1e-4) if dtype == torch.float32 else dict(atol=0.05 * math.sqrt(M / 64), rtol=2e-2)
+        assert torch.allclose(dW.double(), ref, **tol), float((dW.double() - ref).abs().max())
