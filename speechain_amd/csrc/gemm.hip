@@ -316,7 +316,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
   const int lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int h = lane >> 5, li = lane & 31;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (private L2s); remap so
+  // that each XCD works on a contiguous run of tiles -- the N-tiles sharing one A row-panel then hit the same L2.
+  // (Speed only: any placement gives the same result.)  Bijective for every grid size.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+    if (nwg >= 16) {
+      const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+      const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = id / gx;
+      bx = id - by * gx;
+    }
+  }
+  const int n0 = bx * BN, m0 = by * BM;
   const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
   const unsigned short* A = (const unsigned short*)p.A + z1 * p.sA1 + z2 * p.sA2;
   const unsigned short* B = (const unsigned short*)p.B + z1 * p.sB1 + z2 * p.sB2;

@@ -169,6 +169,40 @@ def gemm(code: int, A, B, C, M: int, N: int, K: int, lda: int, ldb: int, ldc: in
              1 if out_f32 else 0, 1 if accumulate else 0, stream())
 
 
+class _Side:
+    """Runs independent kernels of one backward step (e.g. wgrad next to dgrad) on a second stream and joins before the
+    results are handed back to autograd.  The GEMMs here are latency-bound (~250 workgroups, 1 per CU), so two of them
+    overlap almost perfectly.  Capture-safe (plain event fork/join)."""
+
+    streams = {}
+    enabled = True
+
+    def __init__(self, ref: torch.Tensor):
+        self.on = _Side.enabled and ref.is_cuda
+        if self.on:
+            key = ref.device.index
+            if key not in _Side.streams:
+                _Side.streams[key] = torch.cuda.Stream(device=ref.device)
+            self.side = _Side.streams[key]
+            self.main = torch.cuda.current_stream(ref.device)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K).  The output is small and the contraction long, so in bf16 mode the
     contraction is split across workgroups (sc_gemm_splitk) to fill the chip."""
@@ -245,17 +279,20 @@ class _Linear(torch.autograd.Function):
         dres = dy if has_res else None
         dz = _dropout_apply(dy2, drop_p, seed, off)
         W = weights.fused(ws, x2.dtype)
+        side = _Side(x2)
+        with side:  # parameter gradients next to the data gradient
+            dW = wgrad(code, dz, x2)  # dW = dz^T x
+            dws = list(dW.split(rows, dim=0))
+            dbs = [None] * len(rows)
+            if any(has_b):
+                db = _colsum(dz)
+                dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             gemm(code, _p(dz), _p(W), _p(dx), M, K, N, N, K, K, tb=1)  # dx = dz W
             dx = dx.reshape(xshape)
-        dW = wgrad(code, dz, x2)  # dW = dz^T x
-        dws = list(dW.split(rows, dim=0))
-        dbs = [None] * len(rows)
-        if any(has_b):
-            db = _colsum(dz)
-            dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
+        side.join()
         return (dx, dres, None, None, *dws, *dbs)
 
 
@@ -360,19 +397,23 @@ class _FFN(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dz = _dropout_apply(dy2, p_res, s2, o2)
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
-        dW2 = wgrad(code, dz, h)
-        db2 = _colsum(dz) if has_b2 else None
+        side = _Side(x2)
+        with side:
+            dW2 = wgrad(code, dz, h)
+            db2 = _colsum(dz) if has_b2 else None
         # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
         dpre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
         gemm(code, _p(dz), _p(W2), _p(dpre), M, Fd, K, K, Fd, Fd, tb=1, act=act, aux=_p(h_pre), ldaux=Fd, aux_mode=2,
              drop=(p_h, s1, o1))
-        dW1 = wgrad(code, dpre, x2)
-        db1 = _colsum(dpre) if has_b1 else None
+        with side:
+            dW1 = wgrad(code, dpre, x2)
+            db1 = _colsum(dpre) if has_b1 else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             gemm(code, _p(dpre), _p(W1), _p(dx), M, K, Fd, Fd, K, K, tb=1)
             dx = dx.reshape(xshape)
+        side.join()
         return dx, (dy if has_res else None), dW1, db1, dW2, db2, None, None, None
 
 
@@ -494,17 +535,20 @@ class _AttnCore(torch.autograd.Function):
         zs = (H * Tq * ld, Tq * ld)
         # dPd = dout V^T
         dP = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
+        side = _Side(q_buf)
+        with side:  # dV = Pd^T dout, independent of the dP -> dS -> dQ/dK chain
+            gemm(code, _p(Pv), _p(dout), _p(dkv_buf, iv * d), Tk, dh, Tq, ld, d, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H), sA=zs,
+                 sB=(Tq * d, dh), sC=(dkv_buf.stride(0), dh))
         gemm(code, _p(dout), _p(kv_buf, iv * d), _p(dP), Tq, Tk, dh, d, ldk, ld, nb=(B, H), sA=(Tq * d, dh), sB=(skb, dh), sC=zs)
-        # dV = Pd^T dout
-        gemm(code, _p(Pv), _p(dout), _p(dkv_buf, iv * d), Tk, dh, Tq, ld, d, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H), sA=zs,
-             sB=(Tq * d, dh), sC=(dkv_buf.stride(0), dh))
         # dS (w.r.t. the unscaled products) = scale * P * (dP - rowsum(dP * P)), written in place over dP
         lib.call("sc_softmax_bwd", code, _p(P), _p(dP), _p(dP), Z * Tq, Tk, ld, float(scale), float(drop_p), seed, off, stream())
         # dQ = dS K ;  dK = dS^T Q
+        with side:
+            gemm(code, _p(dP), _p(q_buf, iq * d), _p(dkv_buf, ik * d), Tk, dh, Tq, ld, ldq, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H),
+                 sA=zs, sB=(sqb, dh), sC=(dkv_buf.stride(0), dh))
         gemm(code, _p(dP), _p(kv_buf, ik * d), _p(dq_buf, iq * d), Tq, dh, Tk, ld, ldk, dq_buf.stride(1), tb=1, nb=(B, H), sA=zs,
              sB=(skb, dh), sC=(dq_buf.stride(0), dh))
-        gemm(code, _p(dP), _p(q_buf, iq * d), _p(dkv_buf, ik * d), Tk, dh, Tq, ld, ldq, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H),
-             sA=zs, sB=(sqb, dh), sC=(dkv_buf.stride(0), dh))
+        side.join()
         return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
 
 
