@@ -124,45 +124,87 @@ class ASRTrainStepWorkload:
         self.params = [p for m in (self.prenet, self.model) for p in m.parameters()]
         self.reducer = GradBucketReducer(self.params, bucket_mb=32.0)
         self.reducer.broadcast_parameters()
-        try:
-            self.opt = torch.optim.Adam(self.params, lr=2e-3, betas=(0.9, 0.98), eps=1e-9, fused=True)
-        except Exception:
-            self.opt = torch.optim.Adam(self.params, lr=2e-3, betas=(0.9, 0.98), eps=1e-9, foreach=True)
+        self.lr = torch.tensor(2e-3, device=device)
+        self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)
         torch.manual_seed(1234 + seed)
         self.wave, self.lens, _ = synth_batch(seed, device)
         self.text, self.text_len = synth_text(seed, device)
+        self.feat = torch.zeros(BATCH, 1001, 80, device=device)      # static inputs of the captured region
+        self.flen = torch.zeros(BATCH, dtype=torch.int64, device=device)
         self.nstep = 0
         self.ev, self.flops = [], 0.0
         self.world = world
+        self.g_body = self.g_tail = None
+        self.loss = None
+        self.use_graph = os.environ.get("BENCH_NO_GRAPH", "0") != "1"
 
-    def step(self, timed: bool):
-        from speechain_amd._lib import lib
+    # ---- the two device-side halves of a step; eager or replayed from hipGraphs --------------------------------------
+    def _body(self):
+        """zero grads -> prenet -> encoder/decoder/heads/losses -> backward (parameter grads land in the flat buckets)."""
+        from speechain_amd import functional as Fn
 
-        self.nstep += 1
-        sample = timed and (self.nstep % 4 == 0)  # HIP events around every GEMM launch on one timed step in four
-        lib.timing = {"sc_gemm": self.ev} if sample else None
-        lib.flop_log = [] if sample else None
-        for g in self.opt.param_groups:  # Noam schedule, warmup 25000 (optim_sche/noam.py:42-59)
-            g["lr"] = 2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5
+        Fn.DropoutState.advance()
         self.reducer.zero_grad()
-        with torch.no_grad():
-            feat, flen = self.fe(self.wave, self.lens)
-            feat, flen = self.sa(feat, flen)
-        x, xlen = self.prenet(feat, flen)
+        x, xlen = self.prenet(self.feat, self.flen)
         out = self.model(x, xlen, self.text, self.text_len)
         out["loss"].backward()
-        self.reducer.wait()
+        return out["loss"].detach()
+
+    def _tail(self):
+        """global-norm clip at 5.0 (no host sync) -> fused Adam."""
         flats = [b["flat"] for b in self.reducer.buckets]
         norm = torch.sqrt(sum((f * f).sum() for f in flats))
         coef = torch.clamp(5.0 / (norm + 1e-6), max=1.0)
         for f in flats:
             f.mul_(coef)
         self.opt.step()
-        if sample:
+
+    def _capture(self):
+        from speechain_amd import functional as Fn
+
+        Fn.weights.invalidate()  # the captured graph must contain the weight casts
+        torch.cuda.synchronize()
+        self.g_body = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_body):
+            self.loss = self._body()
+        self.g_tail = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_tail):
+            self._tail()
+        torch.cuda.synchronize()
+
+    def step(self, timed: bool, instrument: bool = False):
+        from speechain_amd import functional as Fn
+        from speechain_amd._lib import lib
+
+        self.nstep += 1
+        # Noam schedule, warmup 25000 (optim_sche/noam.py:42-59): a scalar fill outside the graphs
+        self.lr.fill_(2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5)
+        with torch.no_grad():  # frontend + SpecAugment stay eager: SpecAugment's index draws read the lengths on the host
+            feat, flen = self.fe(self.wave, self.lens)
+            feat, flen = self.sa(feat, flen)
+            self.feat.copy_(feat)
+            self.flen.copy_(flen)
+        graph = self.use_graph and not instrument and self.nstep > 3
+        if graph and self.g_body is None:
+            self._capture()
+        if graph:
+            self.g_body.replay()
+            if self.world > 1:
+                self.reducer.reduce_all_now()
+            self.g_tail.replay()
+            return self.loss
+        if instrument:  # HIP events around every GEMM launch of this (eager) step
+            Fn.weights.invalidate()
+            lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev}
+            lib.flop_log = []
+        loss = self._body()
+        self.reducer.wait()
+        self._tail()
+        if instrument:
             self.flops += sum(lib.flop_log)
-        lib.timing = None
-        lib.flop_log = None
-        return out["loss"]
+            lib.timing = None
+            lib.flop_log = None
+        return loss
 
     def roofline(self):
         ms = sum(a.elapsed_time(b) for a, b in self.ev)
@@ -171,7 +213,8 @@ class ASRTrainStepWorkload:
         return {"bound": "mfma", "kernel": self.dominant, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
                 "launches_timed": n, "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops,
-                "note": "sum of 2*M*N*K*batch over the sampled sc_gemm launches / sum of their HIP-event durations"}
+                "note": "one timed step runs eagerly with HIP events around every sc_gemm/sc_gemm_splitk launch (the other "
+                        "steps replay hipGraphs): sum of 2*M*N*K*batch / sum of the event durations"}
 
 
 def cpu_baseline_train(seconds: float):
@@ -272,8 +315,11 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(True)
+    for i in range(args.steps):
+        if args.workload == "asr_train_step":
+            wl.step(True, instrument=(i == args.steps // 2))  # one eager, event-instrumented step inside the timed region
+        else:
+            wl.step(True)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -84,12 +84,13 @@ int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, i
  * 99-106,131, feed_forward.py:93-101 and speechain/module/postnet/token.py:49.
  * Epilogue, in order: v = alpha*acc + bias[n];  pre_out <- v (optional);
  *   aux_mode 2: v *= act'(aux[m][n])  else  v = act(v)   (act: 0 none, 1 ReLU, 2 exact GELU);
- *   dropout(drop_p) with the stateless generator keyed (seed, offset + linear index of (z,m,n));
+ *   dropout(drop_p) with the stateless generator keyed (*seed, offset + linear index of (z,m,n)); `seed` points to a
+ *   device cell so that a captured hipGraph draws fresh masks on every replay once the host bumps the cell;
  *   aux_mode 1: v += aux[m][n];  store as `dtype`, or as float32 when out_f32 (optionally accumulating). */
 int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
             long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2,
             long long sC1, long long sC2, float alpha, const float* bias, int act, void* pre_out, const void* aux,
-            long long ldaux, int aux_mode, float drop_p, unsigned long long seed, unsigned long long offset, int out_f32,
+            long long ldaux, int aux_mode, float drop_p, const unsigned long long* seed, unsigned long long offset, int out_f32,
             int accumulate, hipStream_t stream);
 
 /* Split-K form for wgrad-shaped products (small M x N, long contraction K), bf16 operands, f32 output with ldc == N:
@@ -120,9 +121,9 @@ int sc_colsum(int dtype, const void* x, long long R, int N, long long ld, float*
  * dP = dPd * keepmask / (1 - p) regenerated from (seed, offset). */
 int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, int H, int Tq, int Tk, long long ld,
                    const unsigned char* mask, long long mask_b, long long mask_q, int causal, float drop_p,
-                   unsigned long long seed, unsigned long long offset, hipStream_t stream);
+                   const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 int sc_softmax_bwd(int dtype, const void* P, const void* dPd, void* dS, long long rows, int Tk, long long ld, float out_scale,
-                   float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
+                   float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
@@ -152,15 +153,15 @@ int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, l
 
 /* y = dropout(x * xscale + table[t] * (*alpha)) for x (B, T, D), table (>= T, D) f32 (pos_enc.py:168-182). */
 int sc_posenc_fwd(int dtype, const void* x, const float* table, const float* alpha, float xscale, void* y, long long B, int T,
-                  int D, float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream);
+                  int D, float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
 /* y = x * scale * keepmask / (1 - p) with the stateless generator (seed, offset + index). */
-int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, unsigned long long seed,
+int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, const unsigned long long* seed,
                unsigned long long offset, hipStream_t stream);
 
 /* dpre = dy * act'(pre) * keepmask / (1 - p): backward of dropout(act(.)) when the upstream gradient is not a GEMM result. */
 int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
-               unsigned long long seed, unsigned long long offset, hipStream_t stream);
+               const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
 #ifdef __cplusplus
 }

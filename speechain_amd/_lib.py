@@ -72,8 +72,11 @@ class _Lib:
     def call(self, name: str, *args):
         """Calls an int-status entry point; raises RuntimeError(sc_last_error()) on a non-zero status."""
         dll = self.load()
-        if self.flop_log is not None and name == "sc_gemm":
-            self.flop_log.append(2.0 * args[6] * args[7] * args[8] * args[12] * args[13])
+        if self.flop_log is not None:
+            if name == "sc_gemm":
+                self.flop_log.append(2.0 * args[6] * args[7] * args[8] * args[12] * args[13])
+            elif name == "sc_gemm_splitk":
+                self.flop_log.append(2.0 * args[5] * args[6] * args[7])
         rec = self.timing.get(name) if self.timing is not None else None
         if rec is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

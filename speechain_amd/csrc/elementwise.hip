@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* in, vo
 // y[b][t][d] = dropout(x[b][t][d] * xscale + table[t][d] * alpha)
 template <typename T>
 __global__ __launch_bounds__(256) void posenc_kernel(const void* x, const float* table, const float* alpha, float xscale, void* y,
-                                                     long long B, int Tn, int D, float drop_p, unsigned long long seed,
+                                                     long long B, int Tn, int D, float drop_p, const unsigned long long* seed_ptr,
                                                      unsigned long long offset) {
+  const unsigned long long seed = drop_p > 0.f ? *seed_ptr : 0ull;
   const long long n = B * Tn * D;
   const long long td = (long long)Tn * D;
   const float a = alpha ? *alpha : 1.f;
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void posenc_kernel(const void* x, const float*
 // y = x * scale * keepmask / (1 - p)
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const void* x, void* y, long long n, float scale, float drop_p,
-                                                      unsigned long long seed, unsigned long long offset) {
+                                                      const unsigned long long* seed_ptr, unsigned long long offset) {
+  const unsigned long long seed = drop_p > 0.f ? *seed_ptr : 0ull;
   const float keep = scale / (1.f - drop_p);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* x, void* y, lo
 // dpre = dy * act'(pre) * keepmask / (1 - p)     (act: 0 none, 1 ReLU, 2 exact GELU)
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
-                                                      unsigned long long seed, unsigned long long offset) {
+                                                      const unsigned long long* seed_ptr, unsigned long long offset) {
+  const unsigned long long seed = drop_p > 0.f ? *seed_ptr : 0ull;
   const float keep = 1.f / (1.f - drop_p);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -121,9 +124,9 @@ SC_API int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, i
 }
 
 SC_API int sc_posenc_fwd(int dtype, const void* x, const float* table, const float* alpha, float xscale, void* y, long long B,
-                         int T, int D, float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+                         int T, int D, float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(x && table && y && B >= 1 && T >= 1 && D >= 1, "sc_posenc_fwd: bad arguments");
-  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_posenc_fwd: dropout p=%f", drop_p);
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sc_posenc_fwd: dropout p=%f needs a seed cell", drop_p);
   const long long n = B * T * D;
   if (dtype == 0) hipLaunchKernelGGL(posenc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, x, table, alpha, xscale, y, B, T, D, drop_p, seed, offset);
   else hipLaunchKernelGGL(posenc_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, x, table, alpha, xscale, y, B, T, D, drop_p, seed, offset);
@@ -131,10 +134,10 @@ SC_API int sc_posenc_fwd(int dtype, const void* x, const float* table, const flo
   return SC_OK;
 }
 
-SC_API int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, unsigned long long seed,
+SC_API int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, float drop_p, const unsigned long long* seed,
                       unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(x && y && n >= 1, "sc_dropout: bad arguments");
-  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_dropout: dropout p=%f", drop_p);
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sc_dropout: dropout p=%f needs a seed cell", drop_p);
   if (dtype == 0) hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, scale, drop_p, seed, offset);
   else hipLaunchKernelGGL(dropout_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n, scale, drop_p, seed, offset);
   SC_LAUNCH_CHECK("dropout_kernel");
@@ -142,8 +145,8 @@ SC_API int sc_dropout(int dtype, const void* x, void* y, long long n, float scal
 }
 
 SC_API int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
-                      unsigned long long seed, unsigned long long offset, hipStream_t stream) {
-  SC_CHECK_ARG(dy && pre && dpre && n >= 1, "sc_act_bwd: bad arguments");
+                      const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(dy && pre && dpre && n >= 1 && (drop_p == 0.f || seed), "sc_act_bwd: bad arguments");
   if (dtype == 0) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
   else hipLaunchKernelGGL(act_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
   SC_LAUNCH_CHECK("act_bwd_kernel");

@@ -41,7 +41,8 @@ struct GemmArgs {
   long long ldaux;
   int aux_mode;
   float drop_p;
-  unsigned long long seed, offset;
+  const unsigned long long* seed;  // device cell holding the generator's current seed (graph replays draw fresh masks)
+  unsigned long long offset;
   int out_f32;
   int accumulate;
   int a_vec, b_vec;  // 16-byte vector loads allowed for A / B
@@ -87,7 +88,7 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& p, float v, float
     else if (p.act == ACT_GELU) v = gelu_f(v);
   }
   if (p.drop_p > 0.f) {
-    const float u = sc_uniform(p.seed, p.offset + idx);
+    const float u = sc_uniform(*p.seed, p.offset + idx);
     v = (u < p.drop_p) ? 0.f : v * (1.f / (1.f - p.drop_p));
   }
   if (p.aux_mode == AUX_ADD) v += aux;
@@ -623,7 +624,7 @@ int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const ch
 SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
                    long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
                    long long sB2, long long sC1, long long sC2, float alpha, const float* bias, int act, void* pre_out,
-                   const void* aux, long long ldaux, int aux_mode, float drop_p, unsigned long long seed,
+                   const void* aux, long long ldaux, int aux_mode, float drop_p, const unsigned long long* seed,
                    unsigned long long offset, int out_f32, int accumulate, hipStream_t stream) {
   SC_CHECK_ARG(A && B && C, "sc_gemm: null operand");
   SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_gemm: dtype must be 0 (f32) or 1 (bf16)");
@@ -633,6 +634,7 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   SC_CHECK_ARG(aux_mode == AUX_NONE || aux, "sc_gemm: aux_mode %d without aux", aux_mode);
   SC_CHECK_ARG(!accumulate || out_f32, "sc_gemm: accumulate needs an f32 output");
   SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_gemm: dropout p=%f", drop_p);
+  SC_CHECK_ARG(drop_p == 0.f || seed, "sc_gemm: dropout needs a seed cell");
   GemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.nb2 = nb2; a.sA1 = sA1; a.sA2 = sA2; a.sB1 = sB1; a.sB2 = sB2; a.sC1 = sC1; a.sC2 = sC2;

@@ -174,7 +174,8 @@ struct SoftmaxArgs {
   long long mask_b, mask_q;   // strides (mask_q = 0 broadcasts over queries)
   int causal;
   float drop_p;
-  unsigned long long seed, offset;
+  const unsigned long long* seed;
+  unsigned long long offset;
 };
 
 template <typename T, int NI>
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
       Row<T>::st(p.P, base + k, pr);
       if (p.Pd) {
         float d = pr;
-        if (p.drop_p > 0.f) d = (uniform01(p.seed, p.offset + base + k) < p.drop_p) ? 0.f : pr * keep;
+        if (p.drop_p > 0.f) d = (uniform01(*p.seed, p.offset + base + k) < p.drop_p) ? 0.f : pr * keep;
         Row<T>::st(p.Pd, base + k, d);
       }
     }
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const void* P, const void* dPd, void* dS, long long rows, int Tk,
                                                           long long ld, float out_scale, float drop_p,
-                                                          unsigned long long seed, unsigned long long offset) {
+                                                          const unsigned long long* seed_ptr, unsigned long long offset) {
+  const unsigned long long seed = drop_p > 0.f ? *seed_ptr : 0ull;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -417,11 +419,11 @@ SC_API int sc_colsum(int dtype, const void* x, long long R, int N, long long ld,
 
 SC_API int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, int H, int Tq, int Tk, long long ld,
                           const unsigned char* mask, long long mask_b, long long mask_q, int causal, float drop_p,
-                          unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+                          const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(S && P, "sc_softmax_fwd: null pointer");
   SC_CHECK_ARG(Z >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && ld >= Tk, "sc_softmax_fwd: bad sizes");
   SC_CHECK_ARG(ld <= 64 * SM_MAX, "sc_softmax_fwd: row length %lld > %d keys", ld, 64 * SM_MAX);
-  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_softmax_fwd: dropout p=%f", drop_p);
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sc_softmax_fwd: dropout p=%f needs a seed cell", drop_p);
   SoftmaxArgs a{S, P, Pd, Z, H, Tq, Tk, ld, mask, mask_b, mask_q, causal, drop_p, seed, offset};
   const long long rows = (long long)Z * Tq;
   SC_DISPATCH_TN(dtype, ld, softmax_fwd_kernel, 4, 8, 16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
@@ -430,7 +432,7 @@ SC_API int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, in
 }
 
 SC_API int sc_softmax_bwd(int dtype, const void* P, const void* dPd, void* dS, long long rows, int Tk, long long ld, float out_scale,
-                          float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+                          float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(P && dPd && dS, "sc_softmax_bwd: null pointer");
   SC_CHECK_ARG(rows >= 1 && Tk >= 1 && ld >= Tk && ld <= 64 * SM_MAX, "sc_softmax_bwd: bad sizes");
   SC_DISPATCH_TN(dtype, ld, softmax_bwd_kernel, 4, 8, 16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, P, dPd, dS, rows, Tk, ld, out_scale,

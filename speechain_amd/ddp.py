@@ -75,6 +75,14 @@ class GradBucketReducer:
             work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._pending.append((work, b["flat"]))
 
+    def reduce_all_now(self):
+        """Launches every bucket's all-reduce (used when backward ran inside a captured hipGraph, where the per-parameter
+        hooks do not fire) and waits for them."""
+        for b in self.buckets:
+            b["ready"] = -1
+            self._launch(b)
+        self.wait()
+
     def broadcast_parameters(self, src: int = 0):
         """One-off parameter (and nothing else) broadcast at start-up."""
         if self.world == 1:

@@ -37,22 +37,44 @@ def _up(n: int, m: int) -> int:
 
 
 class DropoutState:
-    """Process-wide counter-based generator state: seed follows torch.manual_seed, offsets never repeat."""
+    """Counter-based generator state.  The seed lives in a DEVICE cell (one per GPU) that kernels dereference, so a
+    captured hipGraph draws fresh masks on every replay after :meth:`advance`; offsets are handed out from a host counter
+    that ``advance`` resets (every step then uses the same offsets under a new seed).  Without ``advance`` the offsets
+    simply keep growing, which is just as valid."""
 
-    seed = None
+    base_seed = None
     offset = 0
+    cells = {}
 
     @classmethod
-    def next(cls, numel: int) -> Tuple[int, int]:
-        if cls.seed is None:
-            cls.seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+    def _cell(cls, device: torch.device) -> torch.Tensor:
+        key = device.index
+        if key not in cls.cells:
+            if cls.base_seed is None:
+                cls.base_seed = torch.initial_seed() & 0x3FFFFFFFFFFFFFFF
+            cls.cells[key] = torch.tensor([cls.base_seed], dtype=torch.int64, device=device)
+        return cls.cells[key]
+
+    @classmethod
+    def next(cls, numel: int, device: torch.device = None) -> Tuple[int, int]:
+        """(address of the device seed cell, offset) for a dropout site covering `numel` elements."""
+        device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         off = cls.offset
         cls.offset += int(numel)
-        return cls.seed, off
+        return cls._cell(device).data_ptr(), off
+
+    @classmethod
+    def advance(cls):
+        """New seed for the next step (a device-side add: capturable), offsets restart from zero."""
+        for c in cls.cells.values():
+            c.add_(0x9E3779B97F4A7C15 - (1 << 64))  # odd constant: the int64 cell walks all 2^64 values
+        cls.offset = 0
 
     @classmethod
     def reset(cls, seed: int):
-        cls.seed, cls.offset = seed & 0x7FFFFFFFFFFFFFFF, 0
+        cls.base_seed, cls.offset = seed & 0x3FFFFFFFFFFFFFFF, 0
+        for c in cls.cells.values():
+            c.fill_(cls.base_seed)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -151,6 +173,12 @@ class _WeightCache:
         if all(p.is_leaf for p in params):
             self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
+
+
+    def invalidate(self):
+        """Drops every cached copy (call after parameters were updated behind torch's version counters, e.g. by a
+        replayed hipGraph)."""
+        self.store.clear()
 
 
 weights = _WeightCache()
@@ -254,7 +282,7 @@ class _Linear(torch.autograd.Function):
         b = weights.vector(bs)
         N = W.size(0)
         y = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
-        seed, off = DropoutState.next(M * N) if drop_p > 0 else (0, 0)
+        seed, off = DropoutState.next(M * N, x2.device) if drop_p > 0 else (0, 0)
         res2 = None
         if residual is not None:
             res2 = residual.reshape(M, N)
@@ -316,7 +344,7 @@ class _LinearAct(torch.autograd.Function):
         N = W.size(0)
         pre = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
         h = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
-        seed, off = DropoutState.next(M * N) if drop_p > 0 else (0, 0)
+        seed, off = DropoutState.next(M * N, x2.device) if drop_p > 0 else (0, 0)
         gemm(code, _p(x2), _p(W), _p(h), M, N, K, K, K, N, bias=b.detach() if b is not None else None, act=act, pre_out=_p(pre),
              drop=(drop_p, seed, off))
         ctx.save_for_backward(x2, pre, w)
@@ -369,11 +397,11 @@ class _FFN(torch.autograd.Function):
         Fd = W1.size(0)
         h_pre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
         h = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
-        s1, o1 = DropoutState.next(M * Fd) if p_h > 0 else (0, 0)
+        s1, o1 = DropoutState.next(M * Fd, x2.device) if p_h > 0 else (0, 0)
         gemm(code, _p(x2), _p(W1), _p(h), M, Fd, K, K, K, Fd, bias=b1.detach() if b1 is not None else None, act=act,
              pre_out=_p(h_pre), drop=(p_h, s1, o1))
         y = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-        s2, o2 = DropoutState.next(M * K) if p_res > 0 else (0, 0)
+        s2, o2 = DropoutState.next(M * K, x2.device) if p_res > 0 else (0, 0)
         res2 = None
         if residual is not None:
             res2 = residual.reshape(M, K)
@@ -502,7 +530,7 @@ class _AttnCore(torch.autograd.Function):
         seed = off = 0
         if drop_p > 0:
             Pd = torch.empty_like(S)
-            seed, off = DropoutState.next(S.numel())
+            seed, off = DropoutState.next(S.numel(), dev)
         lib.call("sc_softmax_fwd", code, _p(S), _p(S), _p(Pd), Z, H, Tq, Tk, ld, _p(m8), mb or 0, mq or 0, 1 if causal else 0,
                  float(drop_p), seed, off, stream())
         P = S
@@ -569,7 +597,7 @@ class _PosEnc(torch.autograd.Function):
         x = x.contiguous()
         B, T, D = x.shape
         y = torch.empty_like(x)
-        seed, off = DropoutState.next(x.numel()) if drop_p > 0 else (0, 0)
+        seed, off = DropoutState.next(x.numel(), x.device) if drop_p > 0 else (0, 0)
         tab = table.reshape(-1, D)
         lib.call("sc_posenc_fwd", dcode(x), _p(x), _p(tab), _p(alpha.detach()) if alpha is not None else None, float(xscale), _p(y),
                  B, T, D, float(drop_p), seed, off, stream())

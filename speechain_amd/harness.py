@@ -73,8 +73,8 @@ class ASRTransformer(torch.nn.Module):
         enc_mask = make_mask_from_len(feat_len, max_len=feat.size(1))
         enc, enc_mask, _, _ = self.encoder(feat, enc_mask)
         # the trailing <sos/eos> of every sentence becomes padding, then the last column is dropped (model/ar_asr.py:386-388)
-        dec_in = text.clone()
-        dec_in[torch.arange(text.size(0), device=text.device), text_len - 1] = 0
+        pos = torch.arange(text.size(1), device=text.device)[None, :]
+        dec_in = text.masked_fill(pos == (text_len - 1)[:, None], 0)  # (no indexed assignment: that would sync the host)
         dec_in, dec_len = dec_in[:, :-1], text_len - 1
         tgt_mask = make_mask_from_len(dec_len, max_len=dec_in.size(1))
         dec, _, _, _ = self.decoder(tgt=self.embed(dec_in), src=enc, tgt_mask=tgt_mask, src_mask=enc_mask)

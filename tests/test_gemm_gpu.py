@@ -90,10 +90,11 @@ def test_f32_output_and_accumulate(dtype):
 def test_dropout_epilogue_is_reproducible_and_unbiased():
     M, N, K = 256, 512, 64
     A, B = _mk((M, K), torch.float32, 10), _mk((N, K), torch.float32, 11)
+    seed_ptr, _ = Fn.DropoutState.next(0, A.device)  # address of the device seed cell
     outs = []
     for _ in range(2):
         C = torch.empty(M, N, device="cuda")
-        Fn.gemm(0, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, drop=(0.25, 1234, 77))
+        Fn.gemm(0, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, drop=(0.25, seed_ptr, 77))
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     ref = A @ B.t()
@@ -102,8 +103,14 @@ def test_dropout_epilogue_is_reproducible_and_unbiased():
     assert abs(frac - 0.25) < 0.01
     assert torch.allclose(outs[0][kept], ref[kept] / 0.75, atol=1e-4, rtol=1e-5)
     # the stand-alone dropout kernel regenerates the same mask from (seed, offset)
-    y = Fn._dropout_apply(ref.contiguous(), 0.25, 1234, 77)
+    y = Fn._dropout_apply(ref.contiguous(), 0.25, seed_ptr, 77)
     assert torch.equal(y != 0, kept)
+    # a new step (advance) re-seeds the cell: same offsets, different mask
+    Fn.DropoutState.advance()
+    C2 = torch.empty(M, N, device="cuda")
+    Fn.gemm(0, Fn._p(A), Fn._p(B), Fn._p(C2), M, N, K, K, K, N, drop=(0.25, seed_ptr, 77))
+    assert not torch.equal(C2 != 0, kept)
+    assert abs(1.0 - float((C2 != 0).float().mean()) - 0.25) < 0.01
 
 
 @pytest.mark.parametrize("M,N,K", [(7968, 2048, 512), (2016, 512, 512), (999, 130, 70), (300, 5000, 512)])
