@@ -235,3 +235,59 @@ def test_harness_step(golden, mode):
     close(model.embed.embed.weight.grad, g["g_embed"], gt, "g embed")
     close(model.decoder.trfm_layers[1].encdec_att.k_layer.bias.grad, g["g_dec1_encdec_kb"], gt, "g kb")
     close(model.ctc_layer.linear.weight.grad, g["g_ctc_w"], gt, "g ctc w")
+
+
+def test_hipgraph_replay_matches_eager_steps():
+    """Two identical small models: one trained eagerly, one with the step (fwd + bwd + SGD) captured in a hipGraph and
+    replayed; dropout off so both see identical arithmetic -> identical losses for several steps."""
+    from speechain_amd.harness import ASRTransformer
+
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        V = 29
+
+        def make():
+            torch.manual_seed(7)
+            return ASRTransformer(d_model=64, num_heads=4, enc_layers=2, dec_layers=1, fdfwd_dim=128, vocab_size=V, dropout=0.0,
+                                  posenc_maxlen=100).cuda().train()
+
+        gen = torch.Generator().manual_seed(8)
+        x = torch.randn(4, 30, 64, generator=gen).cuda()
+        xlen = torch.tensor([30, 25, 22, 16]).cuda()
+        text = torch.randint(1, V - 2, (4, 8), generator=gen)
+        tl = torch.tensor([8, 7, 6, 5])
+        for i, l in enumerate(tl):
+            text[i, 0] = V - 1
+            text[i, l - 1] = V - 1
+            text[i, l:] = 0
+        text, tl = text.cuda(), tl.cuda()
+
+        def step(model, opt):
+            opt.zero_grad(set_to_none=False)
+            out = model(x, xlen, text, tl)
+            out["loss"].backward()
+            opt.step()
+            return out["loss"].detach()
+
+        m1, m2 = make(), make()
+        o1 = torch.optim.SGD(m1.parameters(), lr=0.05)
+        o2 = torch.optim.SGD(m2.parameters(), lr=0.05)
+        eager = [float(step(m1, o1)) for _ in range(6)]
+        warm = [float(step(m2, o2)) for _ in range(2)]  # also creates the .grad tensors the graph will reuse
+        Fn.weights.invalidate()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = step(m2, o2)
+        replayed = []
+        for _ in range(3):
+            g.replay()
+            replayed.append(float(loss))
+        torch.cuda.synchronize()
+        # capture itself does not execute: eager steps 0,1 then replays = steps 2,3,4
+        assert warm == eager[:2]
+        for a, b in zip(replayed, eager[2:5]):
+            assert abs(a - b) <= 2e-3 * abs(b), (replayed, eager)
+        assert eager[5] < eager[0]  # and it actually learns
+    finally:
+        Fn.set_compute_dtype(None)
