@@ -6,6 +6,7 @@
 hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the GPU box with the tree.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -16,7 +17,9 @@ OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspeechain_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]
+_SCRATCH = re.compile(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", re.S)
 
 
 def sources():
@@ -39,8 +42,15 @@ def _compile(src, force):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        # a kernel that spills to scratch (e.g. an accumulator array that stopped being unrolled) is a performance bug:
+        # refuse to build it silently
+        spills = [(k, int(n)) for k, n in _SCRATCH.findall(r.stderr) if int(n) > 0]
+        if spills:
+            os.remove(obj)
+            raise RuntimeError(f"{src}: kernels using scratch memory: {spills}")
+        other = [l for l in r.stderr.splitlines() if "warning:" in l or "error:" in l]
+        if other:
+            sys.stderr.write("\n".join(other) + "\n")
     return obj
 
 

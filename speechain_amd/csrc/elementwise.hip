@@ -6,14 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
-  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
-  x ^= x >> 33;
-  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
-}
-
 template <typename T> struct Io;
 template <> struct Io<float> {
   static __device__ __forceinline__ float ld(const void* p, long long i) { return ((const float*)p)[i]; }
@@ -60,7 +52,7 @@ __global__ __launch_bounds__(256) void posenc_kernel(const void* x, const float*
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = Io<T>::ld(x, i) * xscale + table[i % td] * a;
-    if (drop_p > 0.f) v = (uniform01(seed, offset + i) < drop_p) ? 0.f : v * keep;
+    if (drop_p > 0.f) v = sc_dropped(seed, offset + i, sc_drop_threshold(drop_p)) ? 0.f : v * keep;
     Io<T>::st(y, i, v);
   }
 }
@@ -74,7 +66,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* x, void* y, lo
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = Io<T>::ld(x, i);
-    v = (drop_p > 0.f && uniform01(seed, offset + i) < drop_p) ? 0.f : v * keep;
+    v = (drop_p > 0.f && sc_dropped(seed, offset + i, sc_drop_threshold(drop_p))) ? 0.f : v * keep;
     Io<T>::st(y, i, v);
   }
 }
@@ -90,8 +82,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, const void
     float g = Io<T>::ld(dy, i);
     const float x = Io<T>::ld(pre, i);
     if (act == 1) g = x > 0.f ? g : 0.f;
-    else if (act == 2) g *= 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
-    if (drop_p > 0.f) g = (uniform01(seed, offset + i) < drop_p) ? 0.f : g * keep;
+    else if (act == 2) g *= sc_gelu_grad(x);
+    if (drop_p > 0.f) g = sc_dropped(seed, offset + i, sc_drop_threshold(drop_p)) ? 0.f : g * keep;
     Io<T>::st(dpre, i, g);
   }
 }

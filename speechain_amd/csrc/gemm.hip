@@ -40,7 +40,7 @@ struct GemmArgs {
   const void* aux;
   long long ldaux;
   int aux_mode;
-  float drop_p;
+  float drop_p, drop_keep;
   const unsigned long long* seed;  // device cell holding the generator's current seed (graph replays draw fresh masks)
   unsigned long long offset;
   int out_f32;
@@ -50,20 +50,6 @@ struct GemmArgs {
   int splitk;          // > 1: blockIdx.z is a K slice of ksplit_len, raw f32 partial tiles go to slab z of C
   int ksplit_len;
 };
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
-}
-
-// counter-based hash RNG (murmur3 finaliser over seed ^ 64-bit counter): uniform in [0,1)
-__device__ __forceinline__ float sc_uniform(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
-  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
-  x ^= x >> 33;
-  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
-}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -77,20 +63,16 @@ template <> struct Elem<unsigned short> {
 
 constexpr int STG_LD = 68;  // f32 row stride of a wave's 32 x 64 staging tile (272 B: 16-byte aligned, bank-skewed)
 
-__device__ __forceinline__ float epilogue_elem(const GemmArgs& p, float v, float bias, float aux, bool has_aux,
-                                               unsigned long long idx) {
+__device__ __forceinline__ float epilogue_elem(const GemmArgs& p, float v, float bias, float aux, bool dropped, float keep) {
   v = v * p.alpha + bias;
   if (p.aux_mode == AUX_ACT_GRAD) {
     if (p.act == ACT_RELU) v = aux > 0.f ? v : 0.f;
-    else if (p.act == ACT_GELU) v *= gelu_grad_f(aux);
+    else if (p.act == ACT_GELU) v *= sc_gelu_grad(aux);
   } else {
     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-    else if (p.act == ACT_GELU) v = gelu_f(v);
+    else if (p.act == ACT_GELU) v = sc_gelu(v);
   }
-  if (p.drop_p > 0.f) {
-    const float u = sc_uniform(*p.seed, p.offset + idx);
-    v = (u < p.drop_p) ? 0.f : v * (1.f / (1.f - p.drop_p));
-  }
+  v = dropped ? 0.f : v * keep;
   if (p.aux_mode == AUX_ADD) v += aux;
   return v;
 }
@@ -131,12 +113,23 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const float* st
       }
     }
     float pre[8];
+    const bool drop = p.drop_p > 0.f;
+    const unsigned long long idx0 = p.offset + ((unsigned long long)z * p.M + m) * p.N + n;
+    const unsigned long long seed = drop ? *p.seed : 0ull;
+    const unsigned thr = sc_drop_threshold(p.drop_p);
+    const float keep = p.drop_keep;
+    unsigned h = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float bias = (p.bias && j < nv) ? p.bias[n + j] : 0.f;
       pre[j] = v[j] * p.alpha + bias;
-      const unsigned long long idx = ((unsigned long long)z * p.M + m) * p.N + n + j;
-      v[j] = epilogue_elem(p, v[j], bias, has_aux ? aux[j] : 0.f, has_aux, idx);
+      bool dropped = false;
+      if (drop) {
+        const unsigned long long idx = idx0 + j;
+        if (j == 0 || (idx & 1) == 0) h = sc_rand_pair(seed, idx >> 1);
+        dropped = ((h >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr;
+      }
+      v[j] = epilogue_elem(p, v[j], bias, has_aux ? aux[j] : 0.f, dropped, keep);
     }
     if (p.out_f32) {
       float* c = (float*)p.C + ci;
@@ -194,25 +187,223 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const float* st
   }
 }
 
-// acc[2][2] (wave's 64 x 64 result) -> LDS staging -> epilogue, one 32-row half at a time.  `smem_f` is the (now idle)
-// operand staging memory; each wave uses a private 32 x STG_LD f32 slice, so no workgroup barrier is needed.
-template <typename T>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& p, float* smem_f, f32x16 (&acc)[2][2], long long zoffC, int z,
-                                              int m0, int n0, int wid, int lane) {
-  float* stage = smem_f + wid * 32 * STG_LD;
-  const int wr = wid >> 1, wc = wid & 1, h = lane >> 5, li = lane & 31;
+// Fast epilogue of a 32 x 64 staged sub-tile for the common cases: out = alpha * acc (+ bias[n]) stored in the compute dtype.
+// No per-element mode branches: most GEMMs of a step (dgrad, attention products, projections without fused extras) land here.
+template <typename T, bool BIAS>
+__device__ __forceinline__ void epilogue_tile_fast(const GemmArgs& p, const float* stage, long long zoffC, int mbase, int nbase,
+                                                   int lane) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  const int cg = lane & 7;
+  const int n = nbase + cg * 8;
+  if (n >= p.N) return;
+  const int nv = min(8, p.N - n);
+  float bias[8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int j = 0; j < 8; ++j) bias[j] = (BIAS && j < nv) ? p.bias[n + j] : 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it;
+    const int m = mbase + row;
+    if (m >= p.M) continue;
+    const f32x4 s0 = *(const f32x4*)(stage + row * STG_LD + cg * 8);
+    const f32x4 s1 = *(const f32x4*)(stage + row * STG_LD + cg * 8 + 4);
+    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], p.alpha, bias[j]);
+    const long long ci = zoffC + (long long)m * p.ldc + n;
+    if (kBf16) {
+      unsigned short* c = (unsigned short*)p.C + ci;
+      if (nv == 8 && p.c_vec) {
+        uint4 o;
+        o.x = sc_f32_to_bf16(v[0]) | ((unsigned)sc_f32_to_bf16(v[1]) << 16);
+        o.y = sc_f32_to_bf16(v[2]) | ((unsigned)sc_f32_to_bf16(v[3]) << 16);
+        o.z = sc_f32_to_bf16(v[4]) | ((unsigned)sc_f32_to_bf16(v[5]) << 16);
+        o.w = sc_f32_to_bf16(v[6]) | ((unsigned)sc_f32_to_bf16(v[7]) << 16);
+        *(uint4*)c = o;
+      } else {
+        for (int j = 0; j < nv; ++j) c[j] = sc_f32_to_bf16(v[j]);
+      }
+    } else {
+      float* c = (float*)p.C + ci;
+      if (nv == 8 && p.c_vec) {
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int j = 0; j < nv; ++j) c[j] = v[j];
+      }
+    }
+  }
+}
+
+// Fused epilogues with the feature set fixed at compile time (the fully run-time `epilogue_tile` stays as the fallback):
+//   v = alpha*acc + bias;  [PRE: pre_out <- v];  ACTG ? v *= act'(aux) : v = act(v);  dropout (run-time p, hoisted);
+//   [ADD: v += aux];  store in the compute dtype.   ACT: 0 none, 1 ReLU, 2 GELU.
+template <typename T, bool BIAS, int ACT, bool ACTG, bool ADD, bool PRE>
+__device__ __forceinline__ void epilogue_tile_fused(const GemmArgs& p, const float* stage, long long zoffC, int z, int mbase,
+                                                    int nbase, int lane) {
+  constexpr bool kBf16 = sizeof(T) == 2;
+  constexpr bool AUX = ACTG || ADD;
+  const int cg = lane & 7;
+  const int n = nbase + cg * 8;
+  if (n >= p.N) return;
+  const int nv = min(8, p.N - n);
+  const bool vec = nv == 8 && p.c_vec;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = (BIAS && j < nv) ? p.bias[n + j] : 0.f;
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const unsigned thr = sc_drop_threshold(p.drop_p);
+  const float keep = p.drop_keep;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (lane >> 3) + 8 * it;
+    const int m = mbase + row;
+    if (m >= p.M) continue;
+    const f32x4 s0 = *(const f32x4*)(stage + row * STG_LD + cg * 8);
+    const f32x4 s1 = *(const f32x4*)(stage + row * STG_LD + cg * 8 + 4);
+    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    const long long ci = zoffC + (long long)m * p.ldc + n;
+    float aux[8];
+    if (AUX) {
+      const long long ai = zoffC + (long long)m * p.ldaux + n;
+      if (vec) {
+        if (kBf16) {
+          const uint4 u = *(const uint4*)((const unsigned short*)p.aux + ai);
+          const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { aux[2 * j] = __uint_as_float(w[j] << 16); aux[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+        } else {
+          const float4 a0 = *(const float4*)((const float*)p.aux + ai), a1 = *(const float4*)((const float*)p.aux + ai + 4);
+          aux[0] = a0.x; aux[1] = a0.y; aux[2] = a0.z; aux[3] = a0.w; aux[4] = a1.x; aux[5] = a1.y; aux[6] = a1.z; aux[7] = a1.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aux[j] = j < nv ? Elem<T>::load(p.aux, ai + j) : 0.f;
+      }
+    }
+    float pre[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = fmaf(v[j], p.alpha, bias[j]);
+      pre[j] = v[j];
+      if (ACTG) {
+        if (ACT == ACT_RELU) v[j] = aux[j] > 0.f ? v[j] : 0.f;
+        else if (ACT == ACT_GELU) v[j] *= sc_gelu_grad_t<kBf16>(aux[j]);
+      } else {
+        if (ACT == ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        else if (ACT == ACT_GELU) v[j] = sc_gelu_t<kBf16>(v[j]);
+      }
+    }
+    if (drop) {
+      const unsigned long long idx0 = p.offset + ((unsigned long long)z * p.M + m) * p.N + n;
+      unsigned hsh = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long idx = idx0 + j;
+        if (j == 0 || (idx & 1) == 0) hsh = sc_rand_pair(seed, idx >> 1);
+        v[j] = (((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr) ? 0.f : v[j] * keep;
+      }
+    }
+    if (ADD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += aux[j];
+    }
+    if (kBf16) {
+      unsigned short* c = (unsigned short*)p.C + ci;
+      unsigned short* pr = PRE ? (unsigned short*)p.pre_out + ci : nullptr;
+      if (vec) {
+        uint4 o;
+        o.x = sc_f32_to_bf16(v[0]) | ((unsigned)sc_f32_to_bf16(v[1]) << 16);
+        o.y = sc_f32_to_bf16(v[2]) | ((unsigned)sc_f32_to_bf16(v[3]) << 16);
+        o.z = sc_f32_to_bf16(v[4]) | ((unsigned)sc_f32_to_bf16(v[5]) << 16);
+        o.w = sc_f32_to_bf16(v[6]) | ((unsigned)sc_f32_to_bf16(v[7]) << 16);
+        *(uint4*)c = o;
+        if (PRE) {
+          o.x = sc_f32_to_bf16(pre[0]) | ((unsigned)sc_f32_to_bf16(pre[1]) << 16);
+          o.y = sc_f32_to_bf16(pre[2]) | ((unsigned)sc_f32_to_bf16(pre[3]) << 16);
+          o.z = sc_f32_to_bf16(pre[4]) | ((unsigned)sc_f32_to_bf16(pre[5]) << 16);
+          o.w = sc_f32_to_bf16(pre[6]) | ((unsigned)sc_f32_to_bf16(pre[7]) << 16);
+          *(uint4*)pr = o;
+        }
+      } else {
+        for (int j = 0; j < nv; ++j) {
+          c[j] = sc_f32_to_bf16(v[j]);
+          if (PRE) pr[j] = sc_f32_to_bf16(pre[j]);
+        }
+      }
+    } else {
+      float* c = (float*)p.C + ci;
+      float* pr = PRE ? (float*)p.pre_out + ci : nullptr;
+      if (vec) {
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (PRE) {
+          *(float4*)pr = make_float4(pre[0], pre[1], pre[2], pre[3]);
+          *(float4*)(pr + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+        }
+      } else {
+        for (int j = 0; j < nv; ++j) {
+          c[j] = v[j];
+          if (PRE) pr[j] = pre[j];
+        }
+      }
+    }
+  }
+}
+
+// acc[MI][2] (a wave's (MI*32) x 64 result) -> private LDS staging slice -> epilogue functor, one 32 x 64 sub-tile at a
+// time.  Instantiated once per epilogue variant so that every instance is a small, fully unrollable loop (a single loop
+// that dispatched between variants per sub-tile was too big to unroll and pushed the accumulators into scratch).
+template <int MI, typename F>
+__device__ __forceinline__ void run_epilogue(float* stage, f32x16 (&acc)[MI][2], int lane, F&& f) {
+  const int h = lane >> 5, li = lane & 31;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * STG_LD + j * 32 + li] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
-    epilogue_tile<T>(p, stage, zoffC, z, m0 + wr * 64 + i * 32, n0 + wc * 64, lane);
+    f(i);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }
+}
+
+// Epilogue of the generic kernels (attention products, wgrad, f32 parity mode): plain / bias-only fast paths, else the
+// run-time general epilogue.  mrow0 = first row of the wave's tile, ncol0 = first column.
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& p, float* stage, f32x16 (&acc)[MI][2], long long zoffC, int z,
+                                              int mrow0, int ncol0, int lane) {
+  const bool simple = p.act == ACT_NONE && p.aux_mode == AUX_NONE && p.drop_p == 0.f && !p.pre_out && !p.out_f32;
+  if (simple && !p.bias)
+    run_epilogue<MI>(stage, acc, lane, [&](int i) { epilogue_tile_fast<T, false>(p, stage, zoffC, mrow0 + i * 32, ncol0, lane); });
+  else if (simple)
+    run_epilogue<MI>(stage, acc, lane, [&](int i) { epilogue_tile_fast<T, true>(p, stage, zoffC, mrow0 + i * 32, ncol0, lane); });
+  else
+    run_epilogue<MI>(stage, acc, lane, [&](int i) { epilogue_tile<T>(p, stage, zoffC, z, mrow0 + i * 32, ncol0, lane); });
+}
+
+// Epilogue of the LDS-DMA kernel (forward projections / FFN layers / data gradients): additionally the compile-time fused
+// variants used by the transformer layers.
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue_wave_fused(const GemmArgs& p, float* stage, f32x16 (&acc)[MI][2], long long zoffC, int z,
+                                                    int mrow0, int ncol0, int lane) {
+#define SC_RUN(...) run_epilogue<MI>(stage, acc, lane, [&](int i) { __VA_ARGS__(p, stage, zoffC, z, mrow0 + i * 32, ncol0, lane); })
+  if (!p.out_f32 && p.bias) {
+    if (p.aux_mode == AUX_NONE && p.pre_out && p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_GELU, false, false, true>); return; }
+    if (p.aux_mode == AUX_NONE && p.pre_out && p.act == ACT_RELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_RELU, false, false, true>); return; }
+    if (p.aux_mode == AUX_ADD && !p.pre_out && p.act == ACT_NONE) { SC_RUN(epilogue_tile_fused<T, true, ACT_NONE, false, true, false>); return; }
+    if (p.aux_mode == AUX_NONE && !p.pre_out && p.act == ACT_NONE && p.drop_p > 0.f) { SC_RUN(epilogue_tile_fused<T, true, ACT_NONE, false, false, false>); return; }
+  }
+  if (!p.out_f32 && !p.bias && p.aux_mode == AUX_ACT_GRAD && !p.pre_out) {
+    if (p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, false, ACT_GELU, true, false, false>); return; }
+    if (p.act == ACT_RELU) { SC_RUN(epilogue_tile_fused<T, false, ACT_RELU, true, false, false>); return; }
+  }
+#undef SC_RUN
+  epilogue_wave<T, MI>(p, stage, acc, zoffC, z, mrow0, ncol0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -471,7 +662,154 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
     return;
   }
-  epilogue_wave<unsigned short>(p, (float*)smem, acc, zoffC, z, m0, n0, wid, lane);
+  epilogue_wave<unsigned short, 2>(p, (float*)smem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 NT kernel, LDS-DMA pipeline (both operands k-contiguous, K % 32 == 0, 16-byte aligned rows)
+//
+// global_load_lds_dwordx4 writes tiles straight into LDS (no VGPRs, no ds_write -- the VGPR->LDS store path was the
+// bottleneck of the register-staged kernel: 16 KB of ds_write_b128 per K tile cost more LDS cycles than the MFMAs).
+// Four 16 KB stages, three tiles in flight behind counted vmcnt waits and ONE raw s_barrier per K tile.
+// An LDS-DMA wave-instruction writes 1 KB linearly (16 rows x 64 B), so rows cannot be padded; bank conflicts of the
+// ds_read_b128 fragment reads are removed by XOR-swizzling the 16-byte chunk index with (row >> 2) & 3 -- applied to the
+// per-lane SOURCE address when staging and to the read address (the same involution on both sides).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* sc_gptr_t;
+typedef __attribute__((address_space(3))) void* sc_lptr_t;
+
+// Tile configuration: WM x WN waves, each owning MI x 2 accumulators of 32 x 32  ->  tile (WM*MI*32) x (WN*64).
+//   <2,2,2> 128 x 128, 4 waves, 4 stages (64 KB, 2 workgroups / CU)   -- many small tiles for narrow outputs
+//   <2,4,4> 256 x 256, 8 waves, 4 stages (128 KB, 1 workgroup / CU)   -- half the L2->LDS traffic per flop; the mid-size
+//           GEMMs of this model (M ~ 8000, K = 512) are bound by exactly that traffic, not by the matrix cores
+template <int WM, int WN, int MI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf16_nt_dma_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN, TM = WM * MI * 32, TN = WN * 64;
+  constexpr int STAGES = 4, STAGE_ELEMS = (TM + TN) * BK16;
+  constexpr int ACH = TM / 16 / NW, BCH = TN / 16 / NW;  // 1 KB chunks (16 rows) of A / B each wave stages per tile
+  extern __shared__ __attribute__((aligned(1024))) unsigned short dsmem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / WN, wc = wid % WN;
+  const int h = lane >> 5, li = lane & 31;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+    if (nwg >= 16) {
+      const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+      const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = id / gx;
+      bx = id - by * gx;
+    }
+  }
+  const int n0 = bx * TN, m0 = by * TM;
+  const int z = blockIdx.z, z1 = z / p.nb2, z2 = z - z1 * p.nb2;
+  const unsigned short* A = (const unsigned short*)p.A + z1 * p.sA1 + z2 * p.sA2;
+  const unsigned short* B = (const unsigned short*)p.B + z1 * p.sB1 + z2 * p.sB2;
+  const long long zoffC = z1 * p.sC1 + z2 * p.sC2;
+
+  // per-lane source pointers of this wave's chunks: chunk c covers tile rows 16c .. 16c+15; lane l fills LDS slot
+  // (row 16c + l/4, 16-byte slot l&3) from source chunk (l&3) ^ ((row >> 2) & 3).  Rows beyond the matrix are clamped to
+  // the last valid row (their products are never stored).
+  const unsigned short* asrc[ACH];
+  const unsigned short* bsrc[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int row = (wid + NW * i) * 16 + (lane >> 2);
+    asrc[i] = A + (long long)min(m0 + row, p.M - 1) * p.lda + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int row = (wid + NW * i) * 16 + (lane >> 2);
+    bsrc[i] = B + (long long)min(n0 + row, p.N - 1) * p.ldb + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+  }
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK16;
+#define SC_DMA_ISSUE(T)                                                                                                \
+  do {                                                                                                                 \
+    unsigned short* st_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < ACH; ++i_)                                                                 \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + (T) * BK16), (sc_lptr_t)(st_ + (wid + NW * i_) * 512), 16, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < BCH; ++i_)                                                                 \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + (T) * BK16),                                             \
+                                       (sc_lptr_t)(st_ + TM * BK16 + (wid + NW * i_) * 512), 16, 0, 0);                \
+  } while (0)
+
+  if (nk > 0) SC_DMA_ISSUE(0);
+  if (nk > 1) SC_DMA_ISSUE(1);
+  if (nk > 2) SC_DMA_ISSUE(2);
+
+  // fragment read offsets (elements) inside an operand tile: row = base + li, 16-byte chunk (2*ks + h) swizzled
+  int aoff[MI][2], boff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int ra = (wr * MI + i) * 32 + li;
+      aoff[i][ks] = ra * BK16 + (((2 * ks + h) ^ ((ra >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rb = (wc * 2 + j) * 32 + li;
+      boff[j][ks] = rb * BK16 + (((2 * ks + h) ^ ((rb >> 2) & 3)) * 8);
+    }
+  }
+
+  constexpr int LPT = ACH + BCH;  // DMA instructions per wave per tile
+  for (int t = 0; t < nk; ++t) {
+    // tile t must have landed: every wave waits for its own DMA (counted: later tiles stay in flight), then the barrier
+    // makes all waves' pieces visible and proves everyone is done reading the stage that tile t+3 overwrites.
+    const int ahead = min(2, nk - 1 - t);
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nk) SC_DMA_ISSUE(t + 3);
+    const unsigned short* as = dsmem + (t % STAGES) * STAGE_ELEMS;
+    const unsigned short* bs = as + TM * BK16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[MI], b[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(as + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(bs + boff[j][ks]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef SC_DMA_ISSUE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become epilogue staging
+
+  epilogue_wave_fused<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
+}
+
+template <int WM, int WN, int MI>
+int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
+  constexpr int TM = WM * MI * 32, TN = WN * 64;
+  constexpr size_t smem = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short);
+  static_assert(smem >= (size_t)WM * WN * 32 * STG_LD * sizeof(float), "operand stages must cover the epilogue staging");
+  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return sc_set_error(SC_ERR_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  }
+  dim3 grid(sc_cdiv(a.N, TN), sc_cdiv(a.M, TM), nbatch);
+  hipLaunchKernelGGL(kernel, grid, dim3(64 * WM * WN), smem, stream, a);
+  SC_LAUNCH_CHECK("gemm_bf16_nt_dma_kernel");
+  return SC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -588,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  epilogue_wave<float>(p, smem, acc, zoffC, z, m0, n0, wid, lane);
+  epilogue_wave<float, 2>(p, smem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // out[i] (+)= sum_s slab[s][i]   (deterministic split-K second stage)
@@ -639,7 +977,7 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.nb2 = nb2; a.sA1 = sA1; a.sA2 = sA2; a.sB1 = sB1; a.sB2 = sB2; a.sC1 = sC1; a.sC2 = sC2;
   a.alpha = alpha; a.bias = bias; a.act = act; a.pre_out = pre_out; a.aux = aux; a.ldaux = ldaux; a.aux_mode = aux_mode;
-  a.drop_p = drop_p; a.seed = seed; a.offset = offset; a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p); a.seed = seed; a.offset = offset; a.out_f32 = out_f32; a.accumulate = accumulate;
   const long long esz = dtype == 0 ? 4 : 2;
   auto vec_ok = [&](const void* ptr, long long ld, long long s1, long long s2) {
     return ((uintptr_t)ptr % 16 == 0) && ((ld * esz) % 16 == 0) && ((s1 * esz) % 16 == 0) && ((s2 * esz) % 16 == 0);
@@ -656,6 +994,12 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   }
   const int nb = nb1 * nb2;
   if (dtype == 1) {
+    if (!ta && !tb && a.a_vec && a.b_vec && (K % BK16 == 0) && K >= 2 * BK16) {
+      // 256 x 256 tiles when they still give every CU work, else 128 x 128
+      const long long big = (long long)sc_cdiv(M, 256) * sc_cdiv(N, 256) * nb;
+      if (big >= 160) return launch_dma<2, 4, 4>(a, nb, stream);
+      return launch_dma<2, 2, 2>(a, nb, stream);
+    }
     if (!ta && !tb) return launch(gemm_bf16_kernel<false, false>, a, nb, stream, "gemm_bf16<NT>");
     if (!ta && tb) return launch(gemm_bf16_kernel<false, true>, a, nb, stream, "gemm_bf16<NN>");
     if (ta && !tb) return launch(gemm_bf16_kernel<true, false>, a, nb, stream, "gemm_bf16<TT>");

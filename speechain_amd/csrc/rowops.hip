@@ -19,14 +19,6 @@ template <> struct Row<unsigned short> {
   static __device__ __forceinline__ void st(void* p, long long i, float v) { ((unsigned short*)p)[i] = sc_f32_to_bf16(v); }
 };
 
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long x = ctr + seed * 0x9E3779B97F4A7C15ull;
-  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
-  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
-  x ^= x >> 33;
-  return (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
-}
-
 // ---- LayerNorm ---------------------------------------------------------------------------------------------------
 constexpr int LN_MAX = 32;  // elements per lane kept in registers: D <= 64 * 32 = 2048
 
@@ -215,7 +207,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
       Row<T>::st(p.P, base + k, pr);
       if (p.Pd) {
         float d = pr;
-        if (p.drop_p > 0.f) d = (uniform01(*p.seed, p.offset + base + k) < p.drop_p) ? 0.f : pr * keep;
+        if (p.drop_p > 0.f) d = sc_dropped(*p.seed, p.offset + base + k, sc_drop_threshold(p.drop_p)) ? 0.f : pr * keep;
         Row<T>::st(p.Pd, base + k, d);
       }
     }
@@ -241,7 +233,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const void* P, const v
     if (k < Tk) {
       pr[i] = Row<T>::ld(P, base + k);
       float d = Row<T>::ld(dPd, base + k);
-      if (drop_p > 0.f) d = (uniform01(seed, offset + base + k) < drop_p) ? 0.f : d * keep;
+      if (drop_p > 0.f) d = sc_dropped(seed, offset + base + k, sc_drop_threshold(drop_p)) ? 0.f : d * keep;
       dp[i] = d;
       dot += d * pr[i];
     } else {

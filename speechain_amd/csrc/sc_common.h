@@ -64,3 +64,56 @@ __device__ __forceinline__ unsigned short sc_f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+
+// ---- stateless dropout generator -------------------------------------------------------------------------------------
+// One 32-bit hash (lowbias32 finaliser) per PAIR of consecutive elements; element i uses bits [16*(i&1), +16) of the
+// hash of pair i>>1 and is dropped when that 16-bit value is below round(p * 65536).  Cheap enough (2 x v_mul_lo_u32
+// per two elements) to live in GEMM epilogues; every kernel that regenerates a mask uses these two helpers.
+__device__ __forceinline__ unsigned sc_rand_pair(unsigned long long seed, unsigned long long pair) {
+  unsigned x = (unsigned)pair * 0x9E3779B1u;
+  x ^= (unsigned)(pair >> 32) * 0x85EBCA77u;
+  x ^= (unsigned)seed ^ ((unsigned)(seed >> 32) * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned sc_drop_threshold(float p) { return (unsigned)(p * 65536.f + 0.5f); }
+__device__ __forceinline__ bool sc_dropped(unsigned long long seed, unsigned long long idx, unsigned thr16) {
+  const unsigned h = sc_rand_pair(seed, idx >> 1);
+  return ((h >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr16;
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp/v_rcp -- ~4x cheaper than erff in a GEMM epilogue
+__device__ __forceinline__ float sc_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float r = 1.f - poly * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+// 3-term variant (A&S 7.1.25, |error| <= 2.5e-5): used where the result is rounded to bf16 (eps 3.9e-3) anyway
+__device__ __forceinline__ float sc_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.47047f, ax, 1.f));
+  float poly = fmaf(0.7478556f, t, -0.0958798f);
+  poly = fmaf(poly, t, 0.3480242f);
+  const float r = 1.f - poly * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+template <bool FAST>
+__device__ __forceinline__ float sc_gelu_t(float x) {
+  return 0.5f * x * (1.f + (FAST ? sc_erf_fast(x * 0.70710678118654752f) : sc_erf(x * 0.70710678118654752f)));
+}
+template <bool FAST>
+__device__ __forceinline__ float sc_gelu_grad_t(float x) {
+  const float e = FAST ? sc_erf_fast(x * 0.70710678118654752f) : sc_erf(x * 0.70710678118654752f);
+  return 0.5f * (1.f + e) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sc_gelu(float x) { return 0.5f * x * (1.f + sc_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float sc_gelu_grad(float x) {
+  return 0.5f * (1.f + sc_erf(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}

@@ -158,6 +158,29 @@ class _WeightCache:
             self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
 
+    def fused_t(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+        """(K, sum n_i) TRANSPOSED compute-dtype copy of the stacked weights: lets the data-gradient product dx = dz W run in
+        the fast k-contiguous ("NT") GEMM form instead of reading W with its contraction index strided."""
+        cacheable = all(p.is_leaf for p in params)
+        key = (tuple(id(p) for p in params), dtype, "T")
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self.store.get(key) if cacheable else None
+        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
+            hit = None
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        K = params[0].size(1)
+        rows = sum(p.size(0) for p in params)
+        buf = hit[1] if hit is not None else torch.empty(K, rows, dtype=dtype, device=params[0].device)
+        r = 0
+        for p in params:
+            src = p.detach().float().contiguous()
+            lib.call("sc_cast_transpose", BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r), p.size(0), K, rows, stream())
+            r += p.size(0)
+        if cacheable:
+            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+        return buf
+
     def vector(self, params: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
         """float32 concatenation of bias vectors (None if there is no bias)."""
         if params[0] is None:
@@ -248,6 +271,20 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return dW
 
 
+def dgrad(code: int, dz: torch.Tensor, ws: Sequence[torch.Tensor], out: torch.Tensor, **epi):
+    """out (M, K) = dz (M, N) @ W (N, K) [+ fused epilogue].  bf16: k-contiguous product against the cached transposed
+    weights; f32 (parity mode): the exact-f32 kernel reads W directly with its contraction index strided."""
+    M, N = dz.shape
+    K = out.size(1)
+    if code == BF16:
+        Wt = weights.fused_t(ws, dz.dtype)
+        gemm(code, _p(dz), _p(Wt), _p(out), M, K, N, dz.stride(0), N, K, **epi)
+    else:
+        W = weights.fused(ws, dz.dtype)
+        gemm(code, _p(dz), _p(W), _p(out), M, K, N, dz.stride(0), K, K, tb=1, **epi)
+    return out
+
+
 def _colsum(x2d: torch.Tensor) -> torch.Tensor:
     R, N = x2d.shape
     out = torch.empty(N, dtype=torch.float32, device=x2d.device)
@@ -317,9 +354,7 @@ class _Linear(torch.autograd.Function):
                 dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-            gemm(code, _p(dz), _p(W), _p(dx), M, K, N, N, K, K, tb=1)  # dx = dz W
-            dx = dx.reshape(xshape)
+            dx = dgrad(code, dz, ws, torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)  # dx = dz W
         side.join()
         return (dx, dres, None, None, *dws, *dbs)
 
@@ -363,12 +398,9 @@ class _LinearAct(torch.autograd.Function):
             dh2 = dh2.contiguous()
         dpre = torch.empty_like(pre)
         lib.call("sc_act_bwd", code, _p(dh2), _p(pre), _p(dpre), dpre.numel(), act, float(drop_p), seed, off, stream())
-        W = weights.fused([w], x2.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-            gemm(code, _p(dpre), _p(W), _p(dx), M, K, N, N, K, K, tb=1)
-            dx = dx.reshape(xshape)
+            dx = dgrad(code, dpre, [w], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
         dW = wgrad(code, dpre, x2)
         db = _colsum(dpre) if has_b else None
         return dx, dW, db, None, None
@@ -430,17 +462,14 @@ class _FFN(torch.autograd.Function):
             dW2 = wgrad(code, dz, h)
             db2 = _colsum(dz) if has_b2 else None
         # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
-        dpre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
-        gemm(code, _p(dz), _p(W2), _p(dpre), M, Fd, K, K, Fd, Fd, tb=1, act=act, aux=_p(h_pre), ldaux=Fd, aux_mode=2,
-             drop=(p_h, s1, o1))
+        dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), act=act, aux=_p(h_pre), ldaux=Fd,
+                     aux_mode=2, drop=(p_h, s1, o1))
         with side:
             dW1 = wgrad(code, dpre, x2)
             db1 = _colsum(dpre) if has_b1 else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
-            gemm(code, _p(dpre), _p(W1), _p(dx), M, K, Fd, Fd, K, K, tb=1)
-            dx = dx.reshape(xshape)
+            dx = dgrad(code, dpre, [w1], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
         side.join()
         return dx, (dy if has_res else None), dW1, db1, dW2, db2, None, None, None
 
