@@ -106,7 +106,7 @@ class ASRTrainStepWorkload:
 
     def __init__(self, device, seed, world):
         from speechain_amd import functional as Fn
-        from speechain_amd.ddp import GradBucketReducer
+        from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
         from speechain_amd.harness import ASRTransformer, Conv2dSubsample
         from speechain_amd.module.augment.specaug import SpecAugment
         from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
@@ -122,7 +122,7 @@ class ASRTrainStepWorkload:
                 if p.dim() > 1:
                     torch.nn.init.xavier_normal_(p)
         self.params = [p for m in (self.prenet, self.model) for p in m.parameters()]
-        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0)
+        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
         self.lr = torch.tensor(2e-3, device=device)
         self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)

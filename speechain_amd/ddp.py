@@ -17,12 +17,43 @@ import torch
 import torch.distributed as dist
 
 
+def attention_fusion_groups(model: torch.nn.Module):
+    """Parameter groups of a model whose gradients one fused kernel produces: q/k/v weights (and biases) of every
+    speechain_amd attention block, in the order the fused projection stacks them."""
+    from speechain_amd.module.transformer.attention import MultiHeadedAttention
+
+    groups = []
+    for m in model.modules():
+        if isinstance(m, MultiHeadedAttention):
+            groups.append([m.q_layer.weight, m.k_layer.weight, m.v_layer.weight])
+            groups.append([m.q_layer.bias, m.k_layer.bias, m.v_layer.bias])
+    return groups
+
+
 class GradBucketReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, process_group=None,
+                 adjacent: Iterable[Iterable[torch.nn.Parameter]] = (), sinks: bool = True):
+        """`adjacent`: groups of parameters to lay out back to back, in the given order (e.g. the q/k/v weights of an attention
+        block, so that their fused gradient GEMM can write one contiguous slot).  `sinks`: register the slots with
+        ``speechain_amd.functional.GradSinks`` so the backward kernels write gradients in place."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
-        self.params = list(reversed(params))  # backward produces gradients roughly in reverse registration order
+        order = list(reversed(params))  # backward produces gradients roughly in reverse registration order
+        group_of = {}
+        for g in adjacent:
+            g = [p for p in g if p.requires_grad]
+            for p in g:
+                group_of[id(p)] = g
+        self.params, seen = [], set()
+        for p in order:
+            if id(p) in seen:
+                continue
+            for q in group_of.get(id(p), [p]):
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    self.params.append(q)
+        self.use_sinks = sinks
         assert self.params, "no trainable parameters"
         self.device = self.params[0].device
         self.cuda = self.device.type == "cuda"
@@ -48,14 +79,26 @@ class GradBucketReducer:
         n = sum(p.numel() for p in plist)
         flat = torch.zeros(n, dtype=torch.float32, device=self.device)
         off = 0
+        views = []
         for p in plist:
-            p.grad = flat[off: off + p.numel()].view_as(p)
+            v = flat[off: off + p.numel()].view_as(p)
+            p.grad = v
+            views.append(v)
+            if self.use_sinks:
+                from speechain_amd.functional import GradSinks
+
+                GradSinks.register(p, flat, off)
             off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, ready=0))
+        self.buckets.append(dict(params=plist, flat=flat, ready=0, views=views, index={id(p): i for i, p in enumerate(plist)}))
 
     def _make_hook(self, bi):
         def hook(param):
             b = self.buckets[bi]
+            if self.use_sinks and self.world > 1:  # the slot must hold the gradient before the bucket is reduced
+                v = b["views"][b["index"][id(param)]]
+                if param.grad is not None and param.grad.data_ptr() != v.data_ptr():
+                    v.copy_(param.grad)
+                    param.grad = v
             b["ready"] += 1
             if b["ready"] == len(b["params"]):
                 self._launch(b)
@@ -78,6 +121,8 @@ class GradBucketReducer:
     def reduce_all_now(self):
         """Launches every bucket's all-reduce (used when backward ran inside a captured hipGraph, where the per-parameter
         hooks do not fire) and waits for them."""
+        if self.use_sinks:
+            self._settle()
         for b in self.buckets:
             b["ready"] = -1
             self._launch(b)
@@ -90,9 +135,23 @@ class GradBucketReducer:
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.pg)
 
+    def _settle(self):
+        """Makes every ``param.grad`` the view of its bucket slot again: gradients produced outside the sink-aware kernels
+        (torch ops, second contributions, cloned tensors) are copied in; parameters without a gradient get zeros."""
+        for b in self.buckets:
+            for p, v in zip(b["params"], b["views"]):
+                g = p.grad
+                if g is None:
+                    v.zero_()
+                elif g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+                p.grad = v
+
     def wait(self):
         """Blocks the optimizer's stream until every bucket is reduced; buckets whose hooks never fired (unused
         parameters) are reduced here so all ranks issue the same collectives."""
+        if self.use_sinks:
+            self._settle()
         for b in self.buckets:
             if b["ready"] != len(b["params"]) and b["ready"] != -1:
                 self._launch(b)
@@ -108,7 +167,18 @@ class GradBucketReducer:
             b["ready"] = 0
 
     def zero_grad(self):
-        """Zeroes the flat buckets (gradients stay views into them)."""
+        """Start of a step.  With gradient sinks the kernels overwrite their slots, so nothing is zeroed: ``param.grad`` is
+        dropped (autograd then adopts the slot view a kernel returns instead of adding into it).  Without sinks the flat
+        buckets are zeroed and gradients stay views into them."""
+        if self.use_sinks:
+            from speechain_amd.functional import GradSinks
+
+            GradSinks.begin_step()
+            for b in self.buckets:
+                for p in b["params"]:
+                    p.grad = None
+                b["ready"] = 0
+            return
         for b in self.buckets:
             b["flat"].zero_()
             b["ready"] = 0

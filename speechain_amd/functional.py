@@ -220,6 +220,50 @@ def gemm(code: int, A, B, C, M: int, N: int, K: int, lda: int, ldb: int, ldc: in
              1 if out_f32 else 0, 1 if accumulate else 0, stream())
 
 
+class GradSinks:
+    """Optional destination registry for parameter gradients.  A trainer (``speechain_amd.ddp.GradBucketReducer``) registers
+    for every parameter a slot inside a flat float32 bucket; the backward kernels then write dW / db / dgamma straight into
+    that slot and hand autograd a view of it, so no per-parameter ``grad += new`` kernel and no gradient copy is left.
+    A parameter that receives a second contribution in the same step falls back to a fresh tensor (autograd adds it)."""
+
+    table = {}
+    used = {}
+    step = 0
+
+    @classmethod
+    def register(cls, param: torch.Tensor, flat: torch.Tensor, offset: int):
+        cls.table[id(param)] = (weakref.ref(param), flat, offset, param.numel())
+
+    @classmethod
+    def clear(cls):
+        cls.table.clear()
+        cls.used.clear()
+
+    @classmethod
+    def begin_step(cls):
+        cls.step += 1
+
+    @classmethod
+    def take(cls, params: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+        """A flat float32 view covering the slots of `params` if they are registered, adjacent in this order and not yet
+        written in this step; else None."""
+        ents = []
+        for p in params:
+            e = cls.table.get(id(p))
+            if e is None or e[0]() is not p or cls.used.get(id(p)) == cls.step:
+                return None
+            ents.append(e)
+        flat, off = ents[0][1], ents[0][2]
+        end = off
+        for e in ents:
+            if e[1] is not flat or e[2] != end:
+                return None
+            end += e[3]
+        for p in params:
+            cls.used[id(p)] = cls.step
+        return flat[off:end]
+
+
 class _Side:
     """Runs independent kernels of one backward step (e.g. wgrad next to dgrad) on a second stream and joins before the
     results are handed back to autograd.  The GEMMs here are latency-bound (~250 workgroups, 1 per CU), so two of them
@@ -254,12 +298,14 @@ class _Side:
             self.main.wait_stream(self.side)
 
 
-def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K).  The output is small and the contraction long, so in bf16 mode the
-    contraction is split across workgroups (sc_gemm_splitk) to fill the chip."""
+def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.Tensor] = ()) -> torch.Tensor:
+    """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K), written into the registered gradient slots of `params` when they
+    have adjacent ones.  The output is small and the contraction long, so in bf16 mode the contraction is split across
+    workgroups (sc_gemm_splitk) to fill the chip."""
     M, N = dz.shape
     K = x2.size(1)
-    dW = torch.empty(N, K, dtype=torch.float32, device=dz.device)
+    sink = GradSinks.take(params) if params else None
+    dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     splitk = min(16, max(1, 512 // tiles), max(1, M // 256))
     if code == BF16 and splitk >= 2:
@@ -285,9 +331,10 @@ def dgrad(code: int, dz: torch.Tensor, ws: Sequence[torch.Tensor], out: torch.Te
     return out
 
 
-def _colsum(x2d: torch.Tensor) -> torch.Tensor:
+def _colsum(x2d: torch.Tensor, params: Sequence[torch.Tensor] = ()) -> torch.Tensor:
     R, N = x2d.shape
-    out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    sink = GradSinks.take(params) if params else None
+    out = sink if sink is not None else torch.empty(N, dtype=torch.float32, device=x2d.device)
     ws = torch.empty(lib.value("sc_colsum_workspace", R, N), dtype=torch.uint8, device=x2d.device)
     lib.call("sc_colsum", dcode(x2d), _p(x2d), R, N, x2d.stride(0), _p(out), _p(ws), ws.numel(), stream())
     return out
@@ -328,6 +375,7 @@ class _Linear(torch.autograd.Function):
         gemm(code, _p(x2), _p(W), _p(y), M, N, K, K, K, N, bias=b, aux=_p(res2), ldaux=N, aux_mode=1 if res2 is not None else 0,
              drop=(drop_p, seed, off))
         ctx.save_for_backward(x2, *ws)
+        ctx.bias_params = [bb for bb in bs if bb is not None]
         ctx.meta = (x.shape, drop_p, seed, off, [w.size(0) for w in ws], [bb is not None for bb in bs], residual is not None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -346,11 +394,11 @@ class _Linear(torch.autograd.Function):
         W = weights.fused(ws, x2.dtype)
         side = _Side(x2)
         with side:  # parameter gradients next to the data gradient
-            dW = wgrad(code, dz, x2)  # dW = dz^T x
+            dW = wgrad(code, dz, x2, ws)  # dW = dz^T x
             dws = list(dW.split(rows, dim=0))
             dbs = [None] * len(rows)
             if any(has_b):
-                db = _colsum(dz)
+                db = _colsum(dz, ctx.bias_params if all(has_b) else ())
                 dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
         dx = None
         if ctx.needs_input_grad[0]:
@@ -383,6 +431,7 @@ class _LinearAct(torch.autograd.Function):
         gemm(code, _p(x2), _p(W), _p(h), M, N, K, K, K, N, bias=b.detach() if b is not None else None, act=act, pre_out=_p(pre),
              drop=(drop_p, seed, off))
         ctx.save_for_backward(x2, pre, w)
+        ctx.bias_params = [b] if b is not None else []
         ctx.meta = (x.shape, act, drop_p, seed, off, b is not None)
         return h.reshape(*x.shape[:-1], N)
 
@@ -401,8 +450,8 @@ class _LinearAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dgrad(code, dpre, [w], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
-        dW = wgrad(code, dpre, x2)
-        db = _colsum(dpre) if has_b else None
+        dW = wgrad(code, dpre, x2, [w])
+        db = _colsum(dpre, ctx.bias_params) if has_b else None
         return dx, dW, db, None, None
 
 
@@ -442,6 +491,7 @@ class _FFN(torch.autograd.Function):
         gemm(code, _p(h), _p(W2), _p(y), M, K, Fd, Fd, Fd, K, bias=b2.detach() if b2 is not None else None, aux=_p(res2), ldaux=K,
              aux_mode=1 if res2 is not None else 0, drop=(p_res, s2, o2))
         ctx.save_for_backward(x2, h_pre, h, w1, w2)
+        ctx.bias_params = [[b1] if b1 is not None else [], [b2] if b2 is not None else []]
         ctx.meta = (x.shape, act, p_h, s1, o1, p_res, s2, o2, b1 is not None, b2 is not None, residual is not None)
         return y.reshape(x.shape)
 
@@ -459,14 +509,14 @@ class _FFN(torch.autograd.Function):
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
         side = _Side(x2)
         with side:
-            dW2 = wgrad(code, dz, h)
-            db2 = _colsum(dz) if has_b2 else None
+            dW2 = wgrad(code, dz, h, [w2])
+            db2 = _colsum(dz, ctx.bias_params[1]) if has_b2 else None
         # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
         dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), act=act, aux=_p(h_pre), ldaux=Fd,
                      aux_mode=2, drop=(p_h, s1, o1))
         with side:
-            dW1 = wgrad(code, dpre, x2)
-            db1 = _colsum(dpre) if has_b1 else None
+            dW1 = wgrad(code, dpre, x2, [w1])
+            db1 = _colsum(dpre, ctx.bias_params[0]) if has_b1 else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dgrad(code, dpre, [w1], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
@@ -499,6 +549,7 @@ class _LayerNorm(torch.autograd.Function):
         lib.call("sc_layernorm_fwd", dcode(x2), _p(x2), _p(gamma.detach()), _p(beta.detach()), _p(y), _p(mean), _p(rstd), R, D,
                  float(eps), stream())
         ctx.save_for_backward(x2, mean, rstd, gamma)
+        ctx.beta_param = beta
         ctx.xshape = x.shape
         return y.reshape(x.shape)
 
@@ -510,8 +561,9 @@ class _LayerNorm(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = torch.empty_like(x2)
-        dg = torch.empty(D, dtype=torch.float32, device=x2.device)
-        db = torch.empty(D, dtype=torch.float32, device=x2.device)
+        sg, sb = GradSinks.take([gamma]), GradSinks.take([ctx.beta_param])
+        dg = sg if sg is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
+        db = sb if sb is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         ws = torch.empty(lib.value("sc_layernorm_bwd_workspace", R, D), dtype=torch.uint8, device=x2.device)
         lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
                  _p(ws), ws.numel(), stream())

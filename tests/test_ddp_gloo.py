@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    red = GradBucketReducer(model.parameters(), bucket_mb=0.005)  # ~1300 floats per bucket -> several buckets
+    red = GradBucketReducer(model.parameters(), bucket_mb=0.005, adjacent=[[model[2].weight, model[0].weight]])  # ~1300 floats per bucket
     red.broadcast_parameters()
     assert len(red.buckets) >= 3
     opt = torch.optim.SGD(model.parameters(), lr=0.1)

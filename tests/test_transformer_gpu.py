@@ -291,3 +291,47 @@ def test_hipgraph_replay_matches_eager_steps():
         assert eager[5] < eager[0]  # and it actually learns
     finally:
         Fn.set_compute_dtype(None)
+
+
+def test_gradient_sinks_match_plain_autograd():
+    """With GradBucketReducer's sinks the kernels write parameter gradients straight into the flat buckets; the values must
+    equal those of plain autograd accumulation (no reducer), including the fused q/k/v slots."""
+    from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
+    from speechain_amd.harness import ASRTransformer
+
+    Fn.set_compute_dtype(torch.float32)
+    try:
+        V = 23
+
+        def make():
+            torch.manual_seed(11)
+            return ASRTransformer(d_model=64, num_heads=4, enc_layers=2, dec_layers=2, fdfwd_dim=128, vocab_size=V, dropout=0.0,
+                                  posenc_maxlen=100).cuda().train()
+
+        gen = torch.Generator().manual_seed(12)
+        x = torch.randn(3, 20, 64, generator=gen).cuda()
+        xlen = torch.tensor([20, 15, 11]).cuda()
+        text = torch.randint(1, V - 2, (3, 7), generator=gen)
+        tl = torch.tensor([7, 6, 4])
+        for i, l in enumerate(tl):
+            text[i, 0] = V - 1
+            text[i, l - 1] = V - 1
+            text[i, l:] = 0
+        text, tl = text.cuda(), tl.cuda()
+        ref = make()
+        ref(x, xlen, text, tl)["loss"].backward()
+        want = {n: p.grad.clone() for n, p in ref.named_parameters()}
+        m = make()
+        red = GradBucketReducer(m.parameters(), bucket_mb=0.25, adjacent=attention_fusion_groups(m))
+        for _ in range(2):  # twice: the second step must not see stale slots or double counting
+            red.zero_grad()
+            m(x, xlen, text, tl)["loss"].backward()
+            red.wait()
+        flat_ranges = [(b["flat"].data_ptr(), b["flat"].data_ptr() + 4 * b["flat"].numel()) for b in red.buckets]
+        for n, p in m.named_parameters():
+            assert p.grad is not None, n
+            assert any(lo <= p.grad.data_ptr() < hi for lo, hi in flat_ranges), n
+            assert torch.allclose(p.grad, want[n], atol=1e-5, rtol=1e-4), (n, float((p.grad - want[n]).abs().max()))
+    finally:
+        Fn.GradSinks.clear()
+        Fn.set_compute_dtype(None)
