@@ -144,6 +144,7 @@ class ASRTrainStepWorkload:
         from speechain_amd import functional as Fn
 
         Fn.DropoutState.advance()
+        Fn.weights.refresh()  # one launch re-casts every bf16 weight copy (plain, fused q|k|v, transposed)
         self.reducer.zero_grad()
         x, xlen = self.prenet(self.feat, self.flen)
         out = self.model(x, xlen, self.text, self.text_len)
@@ -162,7 +163,6 @@ class ASRTrainStepWorkload:
     def _capture(self):
         from speechain_amd import functional as Fn
 
-        Fn.weights.invalidate()  # the captured graph must contain the weight casts
         torch.cuda.synchronize()
         self.g_body = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_body):
@@ -194,7 +194,6 @@ class ASRTrainStepWorkload:
             self.g_tail.replay()
             return self.loss
         if instrument:  # HIP events around every GEMM launch of this (eager) step
-            Fn.weights.invalidate()
             lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev}
             lib.flop_log = []
         loss = self._body()

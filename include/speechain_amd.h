@@ -151,6 +151,13 @@ int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long*
 int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, long long ld_out, hipStream_t stream);
 
+/* Batched refresh of compute-dtype weight copies in ONE launch.  `desc` is a device array of n_desc records
+ *   struct sc_cast_desc { const float* src; void* dst; void* dst_t; int rows, cols; long long ld_dst, ld_dst_t; int tile0, tiles_x; };
+ * (56 bytes): record i owns tiles [tile0_i, tile0_{i+1}) of 32 x 32 elements of its (rows, cols) float32 matrix,
+ * tiles_x = ceil(cols/32); each tile is written as `dtype_out` to dst (row stride ld_dst) and/or transposed to dst_t
+ * (row stride ld_dst_t); null pointers are skipped.  total_tiles = sum of all records' tiles. */
+int sc_cast_weights(int dtype_out, const void* desc, int n_desc, int total_tiles, hipStream_t stream);
+
 /* y = dropout(x * xscale + table[t] * (*alpha)) for x (B, T, D), table (>= T, D) f32 (pos_enc.py:168-182). */
 int sc_posenc_fwd(int dtype, const void* x, const float* table, const float* alpha, float xscale, void* y, long long B, int T,
                   int D, float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream);

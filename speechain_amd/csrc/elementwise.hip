@@ -88,6 +88,45 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, const void
   }
 }
 
+// One launch refreshing many compute-dtype weight copies: descriptor d covers tiles [tile0, next.tile0) of a (rows, cols)
+// f32 matrix; every 32 x 32 tile is written to dst (same layout, row stride ld_dst) and/or dst_t (transposed, row stride
+// ld_dst_t).  Layout of sc_cast_desc: include/speechain_amd.h.
+struct CastDesc {
+  const float* src;
+  void* dst;
+  void* dst_t;
+  int rows, cols;
+  long long ld_dst, ld_dst_t;
+  int tile0, tiles_x;
+};
+
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_weights_kernel(const CastDesc* desc, int n_desc) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.x;
+  int lo = 0, hi = n_desc - 1;  // last descriptor with tile0 <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int lt = t - d.tile0;
+  const int r0 = (lt / d.tiles_x) * 32, c0 = (lt % d.tiles_x) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    const float v = (r < d.rows && c < d.cols) ? d.src[(long long)r * d.cols + c] : 0.f;
+    tile[j][tx] = v;
+    if (d.dst && r < d.rows && c < d.cols) Io<TO>::st(d.dst, (long long)r * d.ld_dst + c, v);
+  }
+  if (!d.dst_t) return;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < d.cols && r < d.rows) Io<TO>::st(d.dst_t, (long long)c * d.ld_dst_t + r, tile[tx][j]);
+  }
+}
+
 inline unsigned grid_for(long long n) {
   long long b = (n + 255) / 256;
   return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -142,5 +181,13 @@ SC_API int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, lo
   if (dtype == 0) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
   else hipLaunchKernelGGL(act_bwd_kernel<unsigned short>, dim3(grid_for(n)), dim3(256), 0, stream, dy, pre, dpre, n, act, drop_p, seed, offset);
   SC_LAUNCH_CHECK("act_bwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_cast_weights(int dtype_out, const void* desc, int n_desc, int total_tiles, hipStream_t stream) {
+  SC_CHECK_ARG(desc && n_desc >= 1 && total_tiles >= 1, "sc_cast_weights: bad arguments");
+  if (dtype_out == 1) hipLaunchKernelGGL(cast_weights_kernel<unsigned short>, dim3(total_tiles), dim3(256), 0, stream, (const CastDesc*)desc, n_desc);
+  else hipLaunchKernelGGL(cast_weights_kernel<float>, dim3(total_tiles), dim3(256), 0, stream, (const CastDesc*)desc, n_desc);
+  SC_LAUNCH_CHECK("cast_weights_kernel");
   return SC_OK;
 }

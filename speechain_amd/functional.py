@@ -7,6 +7,7 @@ Stateless dropout: each dropout site draws (seed, offset) from :class:`DropoutSt
 identical keep-mask from the saved pair, so no mask tensor is stored.
 """
 import math
+import struct
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -197,6 +198,40 @@ class _WeightCache:
             self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
         return buf
 
+
+    def refresh(self):
+        """Re-casts EVERY cached bf16 copy (plain, fused, transposed) of live parameters in one kernel launch and marks them
+        current.  Call once per training step after the optimizer (or at the top of a captured step): the per-call lookups
+        then all hit, replacing ~250 tiny cast launches by one."""
+        ents = [(k, v) for k, v in self.store.items() if k[1] == torch.bfloat16 and all(r() is not None for r in v[2])]
+        if not ents:
+            return
+        sig = tuple((k, v[1].data_ptr()) for k, v in ents)
+        if getattr(self, "_desc_sig", None) != sig:
+            recs, tile0 = [], 0
+            for k, v in ents:
+                buf, params = v[1], [r() for r in v[2]]
+                transposed = len(k) == 3 and k[2] == "T"
+                r = 0
+                for p in params:
+                    rows, cols = p.shape
+                    tx, ty = (cols + 31) // 32, (rows + 31) // 32
+                    if transposed:
+                        rec = (p.data_ptr(), 0, buf.data_ptr() + 2 * r, rows, cols, 0, buf.size(1), tile0, tx)
+                    else:
+                        rec = (p.data_ptr(), buf.data_ptr() + 2 * r * cols, 0, rows, cols, cols, 0, tile0, tx)
+                    recs.append(struct.pack("<QQQiiqqii", *rec))
+                    tile0 += tx * ty
+                    r += rows
+            dev = ents[0][1][1].device
+            self._desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+            self._desc_n, self._desc_tiles, self._desc_sig = len(recs), tile0, sig
+            self._desc_keys = [k for k, _ in ents]
+        for p in {id(r()): r() for _, v in ents for r in v[2]}.values():
+            assert p.is_contiguous() and p.dtype == torch.float32
+        lib.call("sc_cast_weights", BF16, _p(self._desc), self._desc_n, self._desc_tiles, stream())
+        for k, v in ents:
+            self.store[k] = (tuple((r()._version, r().data_ptr()) for r in v[2]), v[1], v[2])
 
     def invalidate(self):
         """Drops every cached copy (call after parameters were updated behind torch's version counters, e.g. by a

@@ -335,3 +335,26 @@ def test_gradient_sinks_match_plain_autograd():
     finally:
         Fn.GradSinks.clear()
         Fn.set_compute_dtype(None)
+
+
+def test_batched_weight_refresh_matches_lazy_casts():
+    """weights.refresh() re-casts every cached bf16 copy (plain, fused q|k|v, transposed) in one launch; after an in-place
+    parameter update the refreshed copies must equal freshly computed ones."""
+    torch.manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(96, 64, device="cuda"))
+    b = torch.nn.Parameter(torch.randn(40, 64, device="cuda"))
+    c = torch.nn.Parameter(torch.randn(70, 33, device="cuda"))
+    Fn.weights.invalidate()
+    f1 = Fn.weights.fused([a, b], torch.bfloat16)
+    t1 = Fn.weights.fused_t([a, b], torch.bfloat16)
+    c1 = Fn.weights.fused([c], torch.bfloat16)
+    ct = Fn.weights.fused_t([c], torch.bfloat16)
+    with torch.no_grad():
+        for p in (a, b, c):
+            p.mul_(1.5).add_(0.25)
+    Fn.weights.refresh()
+    want = torch.cat([a, b]).detach().bfloat16()
+    assert Fn.weights.fused([a, b], torch.bfloat16).data_ptr() == f1.data_ptr()  # cache hit, same buffers
+    assert torch.equal(f1, want) and torch.equal(t1, want.t())
+    assert torch.equal(c1, c.detach().bfloat16()) and torch.equal(ct, c.detach().bfloat16().t())
+    Fn.weights.invalidate()
