@@ -112,6 +112,7 @@ class ASRTrainStepWorkload:
         from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
 
         Fn.set_compute_dtype(torch.bfloat16)
+        Fn.set_attention_probs(False)  # the train step never reads the attention maps: fused attention, no score tensors in HBM
         torch.manual_seed(0)  # identical initial weights on every rank
         self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()

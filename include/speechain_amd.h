@@ -125,6 +125,25 @@ int sc_softmax_fwd(int dtype, const void* S, void* P, void* Pd, int Z, int H, in
 int sc_softmax_bwd(int dtype, const void* P, const void* dPd, void* dS, long long rows, int Tk, long long ld, float out_scale,
                    float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
+/* Fused attention forward (bf16, head size 64, Tk <= 256): O = dropout(softmax(scale * Q K^T + mask)) V without writing
+ * scores to HBM; replaces attention.py:88-106,131 when the probability tensor is not requested.  Q/K/V element
+ * (b, h, t, d) = ptr[b*x_b + t*ldx + h*64 + d]; O likewise with (o_b, ldo); LSE (B*H, Tq) f32 receives the row
+ * logsumexp for the backward pass.  mask / causal / dropout as in sc_softmax_fwd, with the dropout index of element
+ * (z, q, k) being offset + (z*Tq + q)*round_up(Tk, 8) + k (identical to the unfused path; offset must be even). */
+int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Tq, int Tk,
+                     long long q_b, long long ldq, long long kv_b, long long ldk, long long o_b, long long ldo,
+                     const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
+                     const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
+
+/* Backward of sc_attention_fwd: recomputes the probabilities from Q, K and LSE, regenerates the dropout mask and returns
+ * dQ (element (b,h,t,d) at dQ[b*dq_b + t*lddq + h*64 + d]) and dK / dV (same with dkv_b, lddk).  O is the forward output,
+ * dO its gradient (both (o_b, ldo)). */
+int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                     void* dK, void* dV, int B, int H, int Tq, int Tk, long long q_b, long long ldq, long long kv_b,
+                     long long ldk, long long o_b, long long ldo, long long dq_b, long long lddq, long long dkv_b, long long lddk,
+                     const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
+                     const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
+
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
  * lse[r] is kept for the backward pass, which writes dlogits = grow[r]/temperature * (softmax - (1-eps)*onehot - eps/V). */

@@ -1,0 +1,429 @@
+// Fused scaled-dot-product attention for gfx950 (bf16, head size 64, up to 256 keys) -- the training-path replacement of
+// matmul(q, k^T) * scale -> masked_fill(-inf) -> softmax -> dropout -> matmul(attn, v) at
+// speechain/module/transformer/attention.py:88-106,131 (reference path /root/reference/) when the caller does not ask for
+// the (B, H, Tq, Tk) probability tensor.  Scores never touch HBM; the backward pass recomputes them from Q, K and the
+// saved per-row logsumexp.
+//
+// Forward: one 512-thread workgroup per (batch, head, 64-query tile).  Q tile, all keys and all values of the head live
+// in LDS (padded 144-byte rows); S = scale * Q K^T on the bf16 matrix cores into an f32 LDS image; row softmax with 8 lanes
+// per row (mask byte / causal / length, dropout from the device seed cell); P is written back in place as bf16; O = P V with
+// V fragments read through the transposing LDS read, the two key halves combined through LDS.
+#include "sc_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+constexpr int DH = 64;        // head size
+constexpr int TKMAX = 256;    // keys held in LDS
+constexpr int LDR = 72;       // bf16 row stride of the Q / K / V / dO tiles (64 + 8 pad: 144 B, 16-byte aligned)
+constexpr int LDS_S = 264;    // f32 row stride of the score image (its bf16 view has row stride 528)
+constexpr int LDP = 2 * LDS_S;
+
+struct AttnArgs {
+  const unsigned short* Q;
+  const unsigned short* K;
+  const unsigned short* V;
+  unsigned short* O;
+  float* LSE;
+  long long q_b, ldq, kv_b, ldk, o_b, ldo;
+  const unsigned char* mask;
+  long long mask_b, mask_q;
+  int causal;
+  int B, H, Tq, Tk, ldp;  // ldp: row pitch of the (virtual) probability tensor in the dropout index = Tk rounded up to 8
+  float scale, drop_p, drop_keep;
+  const unsigned long long* seed;
+  unsigned long long offset;
+  // backward only
+  const unsigned short* dO;
+  unsigned short* dQ;
+  unsigned short* dK;
+  unsigned short* dV;
+  long long dq_b, lddq, dkv_b, lddk;
+};
+
+// k-contiguous MFMA 32x32x16 operand fragment: row `row`, elements k0 + 8*(lane>>5) .. +7 of a [rows][ld] bf16 tile
+__device__ __forceinline__ bf16x8_t frag_rowmajor(const unsigned short* tile, int ld, int row, int k0, int lane) {
+  return *(const bf16x8_t*)(tile + row * ld + k0 + (lane >> 5) * 8);
+}
+// transposed operand fragment from a [k][col] tile: column col_base + (lane & 31), rows k0 + 8*(lane>>5) .. +7
+__device__ __forceinline__ bf16x8_t frag_transposed(const unsigned short* tile, int ld, int col_base, int k0, int lane) {
+  const int g = lane >> 4, ip = lane & 15, q = ip >> 2, pp = ip & 3;
+  const unsigned short* a = tile + (k0 + 8 * (g >> 1) + q) * ld + col_base + 16 * (g & 1) + 4 * pp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a + 4 * ld));
+  const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// rows [r0, r0+nrows) x 64 columns of a strided bf16 matrix -> LDS tile with row stride LDR; rows >= valid are zero
+__device__ __forceinline__ void load_rows(unsigned short* tile, const unsigned short* src, long long ld, int r0, int nrows,
+                                          int valid, int tid, int nthreads) {
+  for (int c = tid; c < nrows * 8; c += nthreads) {
+    const int r = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < valid) v = *(const uint4*)(src + (long long)(r0 + r) * ld + ch * 8);
+    *(uint4*)(tile + r * LDR + ch * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Qs = (unsigned short*)smem_raw;            // [64][72]
+  unsigned short* Ks = Qs + 64 * LDR;                         // [256][72]
+  unsigned short* Vs = Ks + TKMAX * LDR;                      // [256][72]
+  float* Ss = (float*)(Vs + TKMAX * LDR);                     // [64][264] f32 (bf16 view: row stride 528)
+  unsigned short* Ps = (unsigned short*)Ss;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int z = blockIdx.y, b = z / p.H, hd = z - b * p.H;
+  const int q0 = blockIdx.x * 64;
+  const unsigned short* Qg = p.Q + b * p.q_b + hd * DH;
+  const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
+  const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
+
+  load_rows(Qs, Qg, p.ldq, q0, 64, p.Tq, tid, 512);
+  load_rows(Ks, Kg, p.ldk, 0, TKMAX, p.Tk, tid, 512);
+  load_rows(Vs, Vg, p.ldk, 0, TKMAX, p.Tk, tid, 512);
+  __syncthreads();
+
+  // ---- S = scale * Q K^T : wave (qs, kq) owns queries qs*32.., keys kq*64.. (two 32-key tiles) ----
+  {
+    const int qs = wid & 1, kq = wid >> 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = frag_rowmajor(Qs, LDR, qs * 32 + li, ks * 16, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8_t bb = frag_rowmajor(Ks, LDR, kq * 64 + t * 32 + li, ks * 16, lane);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Ss[(qs * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + kq * 64 + t * 32 + li] = acc[t][r] * p.scale;
+  }
+  __syncthreads();
+
+  // ---- row softmax: 8 consecutive lanes per query row, 32 keys each; P (with dropout) written back in place as bf16 ----
+  {
+    const int row = tid >> 3, seg = tid & 7;
+    const int qg = q0 + row;
+    const unsigned char* mrow = p.mask ? p.mask + b * p.mask_b + (long long)min(qg, p.Tq - 1) * p.mask_q : nullptr;
+    float v[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int k = seg * 32 + j;
+      bool ok = k < p.Tk;
+      if (ok && mrow) ok = mrow[k] != 0;
+      if (ok && p.causal) ok = k <= qg;
+      v[j] = ok ? Ss[row * LDS_S + k] : -INFINITY;
+      mx = fmaxf(mx, v[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      v[j] = (v[j] == -INFINITY) ? 0.f : __expf(v[j] - mx);
+      s += v[j];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    if (seg == 0 && qg < p.Tq) p.LSE[(long long)z * p.Tq + qg] = s > 0.f ? mx + __logf(s) : -INFINITY;
+    const bool drop = p.drop_p > 0.f;
+    const unsigned long long seed = drop ? *p.seed : 0ull;
+    const unsigned thr = sc_drop_threshold(p.drop_p);
+    const unsigned long long idx0 = p.offset + ((unsigned long long)z * p.Tq + qg) * p.ldp + seg * 32;
+    // all 32 values of this lane are in registers: the in-place bf16 store below cannot clobber unread f32 scores of the
+    // row (its other 7 lanes belong to the same wave and have issued their loads already)
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) {
+      float p0 = v[j] * inv, p1 = v[j + 1] * inv;
+      if (drop) {
+        const unsigned hsh = sc_rand_pair(seed, (idx0 + j) >> 1);
+        p0 = ((hsh & 0xFFFFu) < thr) ? 0.f : p0 * p.drop_keep;
+        p1 = ((hsh >> 16) < thr) ? 0.f : p1 * p.drop_keep;
+      }
+      *(unsigned*)(Ps + row * LDP + seg * 32 + j) = sc_f32_to_bf16(p0) | ((unsigned)sc_f32_to_bf16(p1) << 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- O = P V : wave (qs, dt, kh) owns queries qs*32.., head dims dt*32.., keys kh*128.. ----
+  {
+    const int qs = wid & 1, dt = (wid >> 1) & 1, kh = wid >> 2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k0 = kh * 128 + kk * 16;
+      const bf16x8_t a = frag_rowmajor(Ps, LDP, qs * 32 + li, k0, lane);
+      const bf16x8_t bb = frag_transposed(Vs, LDR, dt * 32, k0, lane);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc, 0, 0, 0);
+    }
+    float* red = (float*)Ks + (qs * 2 + dt) * 32 * 33;  // K is dead: 4 x (32 x 33) f32 reduction slabs
+    __syncthreads();
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + li] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      unsigned short* Og = p.O + b * p.o_b + hd * DH + dt * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int qg = q0 + qs * 32 + row;
+        if (qg < p.Tq) Og[(long long)qg * p.ldo] = sc_f32_to_bf16(acc[r] + red[row * 33 + li]);
+      }
+    }
+  }
+}
+
+
+// Backward: one 512-thread workgroup per (batch, head) sweeping its 64-query tiles.  K and V of the head stay in LDS; per
+// tile S = Q K^T and dP = dO V^T are formed side by side in registers, P = exp(scale*S - lse) (masked), the dropout mask is
+// regenerated, dS = P * (dP - delta) * scale with delta = rowsum(dO * O); P~ (dropped P) and dS go to LDS as bf16 and feed
+// dV += P~^T dO, dK += dS^T Q (accumulated in registers across tiles: every wave owns 32 keys) and dQ = dS K.
+constexpr int LDPB = 264;  // bf16 row stride of the P~ / dS tiles
+
+__global__ __launch_bounds__(512, 1) void attn_bwd_kernel(AttnArgs p, const unsigned short* Og) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Qs = (unsigned short*)smem_raw;   // [64][72]
+  unsigned short* dOs = Qs + 64 * LDR;              // [64][72]
+  unsigned short* Ks = dOs + 64 * LDR;              // [256][72]
+  unsigned short* Vs = Ks + TKMAX * LDR;            // [256][72]
+  unsigned short* Pd = Vs + TKMAX * LDR;            // [64][264]
+  unsigned short* dSs = Pd + 64 * LDPB;             // [64][264]
+  float* rowc = (float*)(dSs + 64 * LDPB);          // [2][64]: lse, delta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int z = blockIdx.x, b = z / p.H, hd = z - b * p.H;
+  const unsigned short* Qg = p.Q + b * p.q_b + hd * DH;
+  const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
+  const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
+  const unsigned short* dOg = p.dO + b * p.o_b + hd * DH;
+  const unsigned short* Ogh = Og + b * p.o_b + hd * DH;
+
+  load_rows(Ks, Kg, p.ldk, 0, TKMAX, p.Tk, tid, 512);
+  load_rows(Vs, Vg, p.ldk, 0, TKMAX, p.Tk, tid, 512);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[t][r] = dv[t][r] = 0.f;
+
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const unsigned thr = sc_drop_threshold(p.drop_p);
+
+  for (int q0 = 0; q0 < p.Tq; q0 += 64) {
+    // K / V fragments are loop-invariant, and hoisting them out of the tile loop (64+ VGPRs) is what pushes this kernel
+    // into scratch: launder the tile bases once per iteration so the reads stay inside it
+    const unsigned short* Kt = Ks;
+    const unsigned short* Vt = Vs;
+    asm volatile("" : "+v"(Kt), "+v"(Vt));
+    // ---- stage Q, dO; delta = rowsum(dO * O); lse ----
+    load_rows(Qs, Qg, p.ldq, q0, 64, p.Tq, tid, 512);
+    {
+      const int r = tid >> 3, ch = tid & 7;
+      uint4 vd = make_uint4(0, 0, 0, 0), vo = make_uint4(0, 0, 0, 0);
+      if (q0 + r < p.Tq) {
+        vd = *(const uint4*)(dOg + (long long)(q0 + r) * p.ldo + ch * 8);
+        vo = *(const uint4*)(Ogh + (long long)(q0 + r) * p.ldo + ch * 8);
+      }
+      *(uint4*)(dOs + r * LDR + ch * 8) = vd;
+      const unsigned wd[4] = {vd.x, vd.y, vd.z, vd.w}, wo[4] = {vo.x, vo.y, vo.z, vo.w};
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dot += __uint_as_float(wd[j] << 16) * __uint_as_float(wo[j] << 16);
+        dot += __uint_as_float(wd[j] & 0xFFFF0000u) * __uint_as_float(wo[j] & 0xFFFF0000u);
+      }
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+      if (ch == 0) {
+        rowc[64 + r] = dot;
+        rowc[r] = (q0 + r < p.Tq) ? p.LSE[(long long)z * p.Tq + q0 + r] : -INFINITY;
+      }
+    }
+    __syncthreads();
+
+    // ---- S and dP tiles of wave (qs, kq); P, P~, dS ----
+    {
+      const int qs = wid & 1, kq = wid >> 1;
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {  // one 32-key tile at a time keeps the register footprint below the spill point
+        f32x16 as, ap;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) as[r] = ap[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8_t aq = frag_rowmajor(Qs, LDR, qs * 32 + li, ks * 16, lane);
+          const bf16x8_t ad = frag_rowmajor(dOs, LDR, qs * 32 + li, ks * 16, lane);
+          const bf16x8_t bk = frag_rowmajor(Kt, LDR, kq * 64 + t * 32 + li, ks * 16, lane);
+          const bf16x8_t bv = frag_rowmajor(Vt, LDR, kq * 64 + t * 32 + li, ks * 16, lane);
+          as = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bk, as, 0, 0, 0);
+          ap = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bv, ap, 0, 0, 0);
+        }
+        const int key = kq * 64 + t * 32 + li;
+        const bool kvalid = key < p.Tk && (p.mask == nullptr || p.mask[b * p.mask_b + key] != 0);  // (B, 1, Tk) masks only
+        const unsigned long long didx = p.offset + ((unsigned long long)z * p.Tq + q0 + qs * 32) * p.ldp + key;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = qs * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int qg = q0 + ql;
+          bool ok = kvalid && qg < p.Tq;
+          if (ok && p.causal) ok = key <= qg;
+          const float lse = rowc[ql];
+          const float pr = (ok && lse != -INFINITY) ? __expf(as[r] * p.scale - lse) : 0.f;
+          float pd = pr, dp = ap[r];
+          if (drop) {
+            const bool dropped = sc_dropped(seed, didx + (unsigned)(((r & 3) + 8 * (r >> 2) + 4 * h) * p.ldp), thr);
+            pd = dropped ? 0.f : pr * p.drop_keep;
+            dp = dropped ? 0.f : dp * p.drop_keep;
+          }
+          const float ds = pr * (dp - rowc[64 + ql]) * p.scale;
+          Pd[ql * LDPB + key] = sc_f32_to_bf16(pd);
+          dSs[ql * LDPB + key] = sc_f32_to_bf16(ds);
+          __builtin_amdgcn_sched_barrier(0);  // keep the 16 element bodies sequential: short live ranges, no spills
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- dV += P~^T dO, dK += dS^T Q for this wave's 32 keys; partial dQ of unit (qs, dt, kh) ----
+    {
+#pragma unroll 1
+      for (int ks = 0; ks < 4; ++ks) {  // contraction over the 64 queries of the tile
+        const bf16x8_t apd = frag_transposed(Pd, LDPB, wid * 32, ks * 16, lane);
+        const bf16x8_t ads = frag_transposed(dSs, LDPB, wid * 32, ks * 16, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8_t bdo = frag_transposed(dOs, LDR, t * 32, ks * 16, lane);
+          const bf16x8_t bq = frag_transposed(Qs, LDR, t * 32, ks * 16, lane);
+          dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apd, bdo, dv[t], 0, 0, 0);
+          dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ads, bq, dk[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int qs = wid & 1, dt = (wid >> 1) & 1, kh = wid >> 2;
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll 2
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k0 = kh * 128 + kk * 16;
+        const bf16x8_t a = frag_rowmajor(dSs, LDPB, qs * 32 + li, k0, lane);
+        const bf16x8_t bb = frag_transposed(Kt, LDR, dt * 32, k0, lane);
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, dq, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();  // every wave is done reading P~: its storage becomes the dQ reduction slabs
+      float* red = (float*)Pd + (qs * 2 + dt) * 32 * 33;
+      if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + li] = dq[r];
+      }
+      __syncthreads();
+      if (kh == 0) {
+        unsigned short* dQg = p.dQ + b * p.dq_b + hd * DH + dt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int qg = q0 + qs * 32 + row;
+          if (qg < p.Tq) dQg[(long long)qg * p.lddq] = sc_f32_to_bf16(dq[r] + red[row * 33 + li]);
+        }
+      }
+    }
+    __syncthreads();  // slabs / Q / dO tiles are rewritten by the next tile
+  }
+
+  // ---- dK, dV of this wave's keys ----
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    unsigned short* dKg = p.dK + b * p.dkv_b + hd * DH + t * 32 + li;
+    unsigned short* dVg = p.dV + b * p.dkv_b + hd * DH + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (key < p.Tk) {
+        dKg[(long long)key * p.lddk] = sc_f32_to_bf16(dk[t][r]);
+        dVg[(long long)key * p.lddk] = sc_f32_to_bf16(dv[t][r]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Tq, int Tk,
+                            long long q_b, long long ldq, long long kv_b, long long ldk, long long o_b, long long ldo,
+                            const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
+                            const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(Q && K && V && O && LSE, "sc_attention_fwd: null pointer");
+  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && Tk <= TKMAX, "sc_attention_fwd: need 1 <= Tk <= %d (got %d)", TKMAX, Tk);
+  SC_CHECK_ARG((long long)B * H <= 65535, "sc_attention_fwd: too many (batch, head) pairs");
+  SC_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && q_b % 8 == 0 && kv_b % 8 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 &&
+                   (uintptr_t)V % 16 == 0, "sc_attention_fwd: operands must be 16-byte aligned with strides multiple of 8");
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed), "sc_attention_fwd: dropout p=%f needs a seed cell", drop_p);
+  SC_CHECK_ARG(offset % 2 == 0, "sc_attention_fwd: the dropout offset must be even");
+  AttnArgs a{};
+  a.Q = (const unsigned short*)Q; a.K = (const unsigned short*)K; a.V = (const unsigned short*)V; a.O = (unsigned short*)O; a.LSE = LSE;
+  a.q_b = q_b; a.ldq = ldq; a.kv_b = kv_b; a.ldk = ldk; a.o_b = o_b; a.ldo = ldo;
+  a.mask = mask; a.mask_b = mask_b; a.mask_q = mask_q; a.causal = causal;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldp = (Tk + 7) / 8 * 8; a.scale = scale; a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p);
+  a.seed = seed; a.offset = offset;
+  const size_t smem = (size_t)(64 + 2 * TKMAX) * LDR * 2 + (size_t)64 * LDS_S * 4;
+  SC_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(sc_cdiv(Tq, 64), B * H), dim3(512), smem, stream, a);
+  SC_LAUNCH_CHECK("attn_fwd_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
+                            void* dK, void* dV, int B, int H, int Tq, int Tk, long long q_b, long long ldq, long long kv_b,
+                            long long ldk, long long o_b, long long ldo, long long dq_b, long long lddq, long long dkv_b,
+                            long long lddk, const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale,
+                            float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(Q && K && V && O && dO && LSE && dQ && dK && dV, "sc_attention_bwd: null pointer");
+  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && Tk <= TKMAX, "sc_attention_bwd: need 1 <= Tk <= %d (got %d)", TKMAX, Tk);
+  SC_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0 && q_b % 8 == 0 && kv_b % 8 == 0 && o_b % 8 == 0 &&
+                   (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 && (uintptr_t)V % 16 == 0 && (uintptr_t)O % 16 == 0 &&
+                   (uintptr_t)dO % 16 == 0, "sc_attention_bwd: operands must be 16-byte aligned with strides multiple of 8");
+  SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed) && offset % 2 == 0, "sc_attention_bwd: bad dropout arguments");
+  SC_CHECK_ARG(mask == nullptr || mask_q == 0, "sc_attention_bwd: only (B, 1, Tk) key masks (mask_q == 0) are supported; use the causal flag");
+  AttnArgs a{};
+  a.Q = (const unsigned short*)Q; a.K = (const unsigned short*)K; a.V = (const unsigned short*)V; a.LSE = const_cast<float*>(LSE);
+  a.q_b = q_b; a.ldq = ldq; a.kv_b = kv_b; a.ldk = ldk; a.o_b = o_b; a.ldo = ldo;
+  a.mask = mask; a.mask_b = mask_b; a.mask_q = mask_q; a.causal = causal;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldp = (Tk + 7) / 8 * 8; a.scale = scale; a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p);
+  a.seed = seed; a.offset = offset;
+  a.dO = (const unsigned short*)dO; a.dQ = (unsigned short*)dQ; a.dK = (unsigned short*)dK; a.dV = (unsigned short*)dV;
+  a.dq_b = dq_b; a.lddq = lddq; a.dkv_b = dkv_b; a.lddk = lddk;
+  const size_t smem = (size_t)(2 * 64 + 2 * TKMAX) * LDR * 2 + (size_t)2 * 64 * LDPB * 2 + 2 * 64 * sizeof(float);
+  SC_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(512), smem, stream, a, (const unsigned short*)O);
+  SC_LAUNCH_CHECK("attn_bwd_kernel");
+  return SC_OK;
+}

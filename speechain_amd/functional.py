@@ -61,7 +61,7 @@ class DropoutState:
         """(address of the device seed cell, offset) for a dropout site covering `numel` elements."""
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         off = cls.offset
-        cls.offset += int(numel)
+        cls.offset += (int(numel) + 1) & ~1  # offsets stay even: masks are generated for pairs of elements
         return cls._cell(device).data_ptr(), off
 
     @classmethod
@@ -696,8 +696,99 @@ class _AttnCore(torch.autograd.Function):
         return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
 
 
+_want_probs = True
+
+
+def set_attention_probs(flag: bool):
+    """True (default, the reference's contract): attention modules return the (B, H, Tq, Tk) probabilities.  False: they
+    return None instead, which lets bf16 attention with head size 64 and <= 256 keys run the fused kernel that never
+    writes scores to HBM (training harnesses that do not read the maps)."""
+    global _want_probs
+    _want_probs = bool(flag)
+
+
+class _AttnFused(torch.autograd.Function):
+    """Fused forward (sc_attention_fwd); the backward pass recomputes the probabilities from the saved logsumexp."""
+
+    @staticmethod
+    def forward(ctx, q_buf, kv_buf, same, iq, ik, iv, H, d, mask, causal, scale, drop_p):
+        if same:
+            kv_buf = q_buf
+        B, Tq = q_buf.shape[:2]
+        Tk = kv_buf.size(1)
+        dev = q_buf.device
+        out = torch.empty(B, Tq, d, dtype=q_buf.dtype, device=dev)
+        lse = torch.empty(B * H, Tq, dtype=torch.float32, device=dev)
+        m8 = None
+        mb = mq = 0
+        if mask is not None:
+            m8 = (mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask).contiguous()
+            mb, mq = m8.stride(0), (m8.stride(1) if m8.size(1) > 1 else 0)
+        ld = _up(Tk, 8)
+        seed, off = DropoutState.next(B * H * Tq * ld, dev) if drop_p > 0 else (0, 0)
+        lib.call("sc_attention_fwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(lse), B, H, Tq, Tk,
+                 q_buf.stride(0), q_buf.stride(1), kv_buf.stride(0), kv_buf.stride(1), out.stride(0), out.stride(1), _p(m8), mb, mq,
+                 1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
+        ctx.save_for_backward(q_buf, kv_buf, m8, lse, out)
+        ctx.meta = (same, iq, ik, iv, H, d, causal, scale, drop_p, seed, off, ld, mb, mq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_buf, kv_buf, m8, lse, out = ctx.saved_tensors
+        same, iq, ik, iv, H, d, causal, scale, drop_p, seed, off, ld, mb, mq = ctx.meta
+        B, Tq = q_buf.shape[:2]
+        Tk = kv_buf.size(1)
+        dh = d // H
+        code = dcode(q_buf)
+        dt, dev = q_buf.dtype, q_buf.device
+        Z = B * H
+        ldq, ldk = q_buf.stride(1), kv_buf.stride(1)
+        sqb, skb = q_buf.stride(0), kv_buf.stride(0)
+        zs = (H * Tq * ld, Tq * ld)
+        dout = dout.contiguous()
+        if mq == 0:  # fused backward: probabilities are recomputed on chip from Q, K and the saved logsumexp
+            dq_buf = torch.empty_like(q_buf)
+            dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
+            lib.call("sc_attention_bwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(dout), _p(lse),
+                     _p(dq_buf, iq * d), _p(dkv_buf, ik * d), _p(dkv_buf, iv * d), B, H, Tq, Tk, sqb, ldq, skb, ldk, out.stride(0),
+                     out.stride(1), dq_buf.stride(0), dq_buf.stride(1), dkv_buf.stride(0), dkv_buf.stride(1), _p(m8), mb, mq,
+                     1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
+            return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
+        # dense (B, Tq, Tk) mask: recompute P (and its dropped copy) exactly as the unfused forward does
+        S = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
+        gemm(code, _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(S), Tq, Tk, dh, ldq, ldk, ld, nb=(B, H), sA=(sqb, dh), sB=(skb, dh),
+             sC=zs, alpha=scale)
+        Pd = torch.empty_like(S) if drop_p > 0 else None
+        lib.call("sc_softmax_fwd", code, _p(S), _p(S), _p(Pd), Z, H, Tq, Tk, ld, _p(m8), mb, mq, 1 if causal else 0, float(drop_p),
+                 seed, off, stream())
+        P, Pv = S, (Pd if Pd is not None else S)
+        dq_buf = torch.empty_like(q_buf)
+        dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
+        dP = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
+        side = _Side(q_buf)
+        with side:
+            gemm(code, _p(Pv), _p(dout), _p(dkv_buf, iv * d), Tk, dh, Tq, ld, d, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H), sA=zs,
+                 sB=(Tq * d, dh), sC=(dkv_buf.stride(0), dh))
+        gemm(code, _p(dout), _p(kv_buf, iv * d), _p(dP), Tq, Tk, dh, d, ldk, ld, nb=(B, H), sA=(Tq * d, dh), sB=(skb, dh), sC=zs)
+        lib.call("sc_softmax_bwd", code, _p(P), _p(dP), _p(dP), Z * Tq, Tk, ld, float(scale), float(drop_p), seed, off, stream())
+        with side:
+            gemm(code, _p(dP), _p(q_buf, iq * d), _p(dkv_buf, ik * d), Tk, dh, Tq, ld, ldq, dkv_buf.stride(1), ta=1, tb=1, nb=(B, H),
+                 sA=zs, sB=(sqb, dh), sC=(dkv_buf.stride(0), dh))
+        gemm(code, _p(dP), _p(kv_buf, ik * d), _p(dq_buf, iq * d), Tq, dh, Tk, ld, ldk, dq_buf.stride(1), tb=1, nb=(B, H), sA=zs,
+             sB=(skb, dh), sC=(dq_buf.stride(0), dh))
+        side.join()
+        return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
+
+
 def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, scale, drop_p):
     same = kv_buf is None or kv_buf is q_buf
+    Tk = (q_buf if same else kv_buf).size(1)
+    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and Tk <= 256
+            and q_buf.stride(1) % 8 == 0 and (same or kv_buf.stride(1) % 8 == 0)):
+        out = _AttnFused.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
+                               float(drop_p))
+        return out, None
     return _AttnCore.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
                            float(drop_p))
 

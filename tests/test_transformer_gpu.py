@@ -358,3 +358,38 @@ def test_batched_weight_refresh_matches_lazy_casts():
     assert torch.equal(f1, want) and torch.equal(t1, want.t())
     assert torch.equal(c1, c.detach().bfloat16()) and torch.equal(ct, c.detach().bfloat16().t())
     Fn.weights.invalidate()
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+@pytest.mark.parametrize("case", ["self_pad", "self_causal", "cross"])
+def test_fused_attention_matches_unfused(case, drop_p):
+    """bf16, head size 64: the fused kernel (no score tensor in HBM) against the GEMM + softmax + GEMM path, forward and
+    gradients, with padding mask, causal flag and dropout (identical masks by construction)."""
+    from speechain_amd.module.transformer.attention import MultiHeadedAttention
+
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(5)
+        d, H, B = 256, 4, 3
+        Tq, Tk = (249, 249) if case != "cross" else (63, 249)
+        m = MultiHeadedAttention(num_heads=H, d_model=d, dropout=drop_p).cuda().train()
+        q = torch.randn(B, Tq, d, device="cuda", requires_grad=True)
+        kv = q if case != "cross" else torch.randn(B, Tk, d, device="cuda", requires_grad=True)
+        lens = torch.tensor([Tk, 200, 131], device="cuda")
+        mask = (torch.arange(Tk, device="cuda")[None, :] < lens[:, None])[:, None, :]
+        w = torch.randn(B, Tq, d, device="cuda")
+        outs = []
+        for fused in (False, True):
+            Fn.set_attention_probs(not fused)
+            Fn.DropoutState.reset(1234)
+            y, p = m(kv, kv, q, mask, _causal=(case == "self_causal"))
+            assert (p is None) == fused
+            g = torch.autograd.grad((y.float() * w).sum(), [q] + ([kv] if case == "cross" else []) + [m.q_layer.weight, m.v_layer.bias])
+            outs.append((y.float(), [t.float() for t in g]))
+        (y0, g0), (y1, g1) = outs
+        assert torch.allclose(y0, y1, atol=2e-2, rtol=2e-2), float((y0 - y1).abs().max())
+        for a, b in zip(g0, g1):
+            assert torch.allclose(a, b, atol=3e-2 * float(a.abs().max()) + 1e-3, rtol=5e-2), float((a - b).abs().max())
+    finally:
+        Fn.set_attention_probs(True)
+        Fn.set_compute_dtype(None)
