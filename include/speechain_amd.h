@@ -37,9 +37,10 @@ int sc_frontend_num_tiles(int n_fft);
 long long sc_frontend_basis_floats(int n_fft);
 
 /* basis <- window (win_length floats on device, centred in n_fft as torch.stft does) x DFT twiddles, built in
- * double precision on the device.  Replaces the lazy torch.<window>_window + the FFT plan of torch.stft
+ * double precision on the device; for n_fft = 400 it also holds the tables of the 16 x 25 prime-factor DFT the kernel then
+ * uses (they depend on hop through the LDS padding).  Replaces the lazy torch.<window>_window + the FFT plan of torch.stft
  * (speech2linear.py:192-198). */
-int sc_frontend_basis_init(const float* window, int win_length, int n_fft, float* basis, hipStream_t stream);
+int sc_frontend_basis_init(const float* window, int win_length, int n_fft, int hop, float* basis, hipStream_t stream);
 
 /* wave (B, T_w) f32 with row stride wave_stride, wave_len (B,) -> any of
  *   out_feat   (B, T, n_mels)  mel filterbank output, clamp+log when `logging` (value = ln(max(x, clamp)) / log_div)

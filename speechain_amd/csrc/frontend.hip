@@ -18,6 +18,7 @@
 // applied on the way in) with one pad word per hop so that the 32 frame rows of an MFMA A-operand hit
 // 32 different banks.  Wave w owns frame tile (w % FT) and column group (w / FT).
 #include "sc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -53,11 +54,94 @@ struct FrontendArgs {
   int off_P, off_O;    // LDS offsets (floats)
   int overlap;         // power image overlaps the sample image (single-pass configuration)
   int tiles_per_group, tiles_per_pass, npasses;
+  const float* pfa;    // tables of the 16 x 25 two-stage DFT (n_fft = 400) or null
 };
 
 __device__ __forceinline__ long long floordiv_ll(long long a, long long b) {
   long long q = a / b;
   return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+
+// Stages the waveform span of frames [t0, t0 + FTF) in LDS: pre-emphasis, reflect padding and tail zeroing applied on the
+// way in; one pad word per hop (padflag) so that consecutive frames start on different banks.
+template <int FTF>
+__device__ __forceinline__ void stage_samples(const FrontendArgs& p, float* smem, int b, int t0, long long wlen, int tid) {
+  const float* x = p.wave + (long long)b * p.wave_stride;
+  const int count = (FTF - 1) * p.hop + p.krows;
+  const long long padded_len = (long long)p.T_w + 2LL * p.pad;
+  const float negc = -p.preemph;
+  for (int i = tid; i < count; i += 256) {
+    const long long j = (long long)t0 * p.hop + i;
+    float v = 0.f;
+    if (j < padded_len) {
+      long long n = j - p.pad;
+      if (n < 0) n = -n;
+      else if (n >= p.T_w) n = 2LL * (p.T_w - 1) - n;
+      if (p.use_preemph) {
+        if (n < wlen) {
+          const float prev = n > 0 ? x[n - 1] : 0.f;
+          v = fmaf(negc, prev, x[n]);
+        }
+      } else {
+        v = x[n];
+      }
+    }
+    smem[i + (i / p.hop) * p.padflag] = v;
+  }
+}
+
+// Per-frame epilogue on the power image P (FTF rows, stride p.PS): banded mel + clamp/log with one lane per frame, frame
+// energy, coalesced copy-out of the mel rows (through the O staging image) and of the optional linear spectrogram.
+template <int FTF>
+__device__ __forceinline__ void frontend_epilogue(const FrontendArgs& p, const float* P, float* O, int b, int t0, int flen,
+                                                  int tid, int lane, int wid) {
+  const int f = lane & (FTF - 1);
+  const int t = t0 + f;
+  const bool live = t < flen;
+  const float* prow = P + f * p.PS;
+
+  if (p.out_feat) {
+    for (int m = wid; m < p.n_mels; m += 4) {
+      const int lo = p.band_lo[m], hi = p.band_hi[m];
+      const float* wrow = p.melw + (long long)m * p.NB;
+      float s = 0.f;
+      for (int k = lo; k < hi; ++k) s = fmaf(prow[k], wrow[k], s);
+      if (!live) s = 0.f;
+      if (p.logging) s = logf(fmaxf(s, p.clamp)) / p.log_div;
+      if (lane < FTF) O[f * p.OS + m] = s;
+    }
+  }
+  if (p.out_energy && wid == 3 && lane < FTF && t < p.T) {
+    float e = 0.f;
+    for (int k = 0; k < p.NB; ++k) {
+      const float v = prow[k];
+      e += p.mag_spec ? v * v : v;
+    }
+    p.out_energy[(long long)b * p.T + t] = live ? sqrtf(fmaxf(e, 1e-10f)) : 0.f;
+  }
+  __syncthreads();
+
+  const int nvalid = min(FTF, p.T - t0);
+  if (p.out_feat) {
+    float* dst = p.out_feat + ((long long)b * p.T + t0) * p.n_mels;
+    const int total = nvalid * p.n_mels;
+    for (int e = tid; e < total; e += 256) {
+      const int ff = e / p.n_mels;
+      const int m = e - ff * p.n_mels;
+      dst[e] = O[ff * p.OS + m];
+    }
+  }
+  if (p.out_linear) {
+    float* dst = p.out_linear + ((long long)b * p.T + t0) * p.NB;
+    const int total = nvalid * p.NB;
+    for (int e = tid; e < total; e += 256) {
+      const int ff = e / p.NB;
+      const int k = e - ff * p.NB;
+      float v = (t0 + ff < flen) ? P[ff * p.PS + k] : 0.f;
+      if (p.lin_logging) v = logf(fmaxf(v, p.lin_clamp)) / p.lin_log_div;
+      dst[e] = v;
+    }
+  }
 }
 
 template <int FT>
@@ -75,31 +159,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendArgs p) {
   if (blockIdx.x == 0 && tid == 0) p.feat_len[b] = flen_ll;
   const int flen = (int)(flen_ll < 0 ? 0 : (flen_ll > p.T ? p.T : flen_ll));
 
-  // ---- stage the waveform span in LDS -----------------------------------------------------------
-  {
-    const float* x = p.wave + (long long)b * p.wave_stride;
-    const int count = (FTF - 1) * p.hop + p.krows;
-    const long long padded_len = (long long)p.T_w + 2LL * p.pad;
-    const float negc = -p.preemph;
-    for (int i = tid; i < count; i += 256) {
-      const long long j = (long long)t0 * p.hop + i;
-      float v = 0.f;
-      if (j < padded_len) {
-        long long n = j - p.pad;
-        if (n < 0) n = -n;
-        else if (n >= p.T_w) n = 2LL * (p.T_w - 1) - n;
-        if (p.use_preemph) {
-          if (n < wlen) {
-            const float prev = n > 0 ? x[n - 1] : 0.f;
-            v = fmaf(negc, prev, x[n]);
-          }
-        } else {
-          v = x[n];
-        }
-      }
-      smem[i + (i / p.hop) * p.padflag] = v;
-    }
-  }
+  stage_samples<FTF>(p, smem, b, t0, wlen, tid);
   __syncthreads();
 
   // ---- windowed DFT on the f32 matrix cores ------------------------------------------------------
@@ -175,53 +235,155 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendArgs p) {
   }
   __syncthreads();
 
-  // ---- per-frame epilogue: one lane per frame -----------------------------------------------------
-  const int f = lane & (FTF - 1);
-  const int t = t0 + f;
-  const bool live = t < flen;
-  const float* prow = P + f * p.PS;
-  float* O = smem + p.off_O;
+  frontend_epilogue<FTF>(p, P, smem + p.off_O, b, t0, flen, tid, lane, wid);
+}
 
-  if (p.out_feat) {
-    for (int m = wid; m < p.n_mels; m += 4) {
-      const int lo = p.band_lo[m], hi = p.band_hi[m];
-      const float* wrow = p.melw + (long long)m * p.NB;
-      float s = 0.f;
-      for (int k = lo; k < hi; ++k) s = fmaf(prow[k], wrow[k], s);
-      if (!live) s = 0.f;
-      if (p.logging) s = logf(fmaxf(s, p.clamp)) / p.log_div;
-      if (lane < FTF) O[f * p.OS + m] = s;
+
+// ---- n_fft = 400: Good-Thomas (prime-factor) two-stage DFT, 400 = 16 x 25 with gcd 1 -> no twiddle factors --------------
+//   input index  n = (25 n1 + 16 n2) mod 400,   output index  k = (225 k1 + 176 k2) mod 400   (CRT maps)
+//   stage 1: 25-point real-input DFTs along n2 for each n1 (k2 = 0..12 suffice: conjugate symmetry)   [32 frames x 26] x [26 x 32]
+//   stage 2: 16-point complex DFTs along n1 for each k2                                              [32 frames x 32] x [32 x 32]
+// both as exact-f32 MFMA products with the (tiny) DFT matrices held in registers; 13 MFMAs per frame instead of the 81 of the
+// direct 400 x 402 product, and FFT-like (short) accumulation chains.  The 208 computed (k1, k2) values cover the 201 bins
+// after folding k > 200 to 400 - k.
+constexpr int PFA_TAB = 16 * 26;
+constexpr int PFA_FLOATS = 26 * 32 + 32 * 32 + 16 * 32 + 2 * PFA_TAB;
+constexpr int PFA_YS = 401;  // Y row stride per frame: 16 * 25 + 1 (odd: conflict-free frame-major reads)
+
+__global__ __launch_bounds__(256, 2) void frontend_pfa400_kernel(FrontendArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int FTF = 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * FTF;
+  const long long wlen = p.wave_len[b];
+  long long flen_ll = floordiv_ll(wlen + 2LL * p.pad - p.n_fft, p.hop) + 1;
+  if (blockIdx.x == 0 && tid == 0) p.feat_len[b] = flen_ll;
+  const int flen = (int)(flen_ll < 0 ? 0 : (flen_ll > p.T ? p.T : flen_ll));
+
+  stage_samples<FTF>(p, smem, b, t0, wlen, tid);
+  __syncthreads();
+
+  const float* W25 = p.pfa;
+  const float* W16c = W25 + 26 * 32;
+  const float* W16r = W16c + 32 * 32;
+  const int* tpos = (const int*)(W16r + 16 * 32);
+  const float* twin = (const float*)(tpos + PFA_TAB);
+  float* Y = smem;              // overlaps the sample image (rewritten only after every wave finished stage 1)
+  float* P = smem + p.off_P;
+
+  // ---- stage 1: wave w transforms n1 = 4w .. 4w+3 ----
+  {
+    float b1[13];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) b1[s] = W25[(2 * s + h) * 32 + li];
+    f32x16 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    const float* frow = smem + li * (p.hop + p.padflag);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n1 = wid * 4 + u;
+#pragma unroll
+      for (int s = 0; s < 13; ++s) {
+        const int idx = n1 * 26 + 2 * s + h;
+        const float a = twin[idx] * frow[tpos[idx]];
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc[u], 0, 0, 0);
+      }
     }
-  }
-  if (p.out_energy && wid == 3 && lane < FTF && t < p.T) {
-    float e = 0.f;
-    for (int k = 0; k < p.NB; ++k) {
-      const float v = prow[k];
-      e += p.mag_spec ? v * v : v;
+    __syncthreads();
+    if (li < 25) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Y[((r & 3) + 8 * (r >> 2) + 4 * h) * PFA_YS + (wid * 4 + u) * 25 + li] = acc[u][r];
     }
-    p.out_energy[(long long)b * p.T + t] = live ? sqrtf(fmaxf(e, 1e-10f)) : 0.f;
   }
   __syncthreads();
 
-  const int nvalid = min(FTF, p.T - t0);
-  if (p.out_feat) {
-    float* dst = p.out_feat + ((long long)b * p.T + t0) * p.n_mels;
-    const int total = nvalid * p.n_mels;
-    for (int e = tid; e < total; e += 256) {
-      const int ff = e / p.n_mels;
-      const int m = e - ff * p.n_mels;
-      dst[e] = O[ff * p.OS + m];
+  // ---- stage 2: k2 = 0 (real input, 8 MFMAs) and k2 = 1..12 (16 MFMAs each): waves take {0,1,2,3} {4,5,6} {7,8,9} {10,11,12}
+  {
+    float b2[16], b0[8];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) b2[s] = W16c[(2 * s + h) * 32 + li];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) b0[s] = W16r[(2 * s + h) * 32 + li];
+    const int kbeg = wid == 0 ? 0 : 1 + 3 * wid, kend = wid == 0 ? 4 : 4 + 3 * wid;
+    const float* yrow = Y + li * PFA_YS;
+    for (int k2 = kbeg; k2 < kend; ++k2) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      if (k2 == 0) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yrow[(2 * s + h) * 25], b0[s], acc, 0, 0, 0);
+      } else {
+        const int comp = h ? 12 + k2 : k2;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yrow[s * 25 + comp], b2[s], acc, 0, 0, 0);
+      }
+      int bin = (225 * (li & 15) + 176 * k2) % 400;
+      if (bin > 200) bin = 400 - bin;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r] * acc[r];
+        v += __shfl_xor(v, 16, 64);
+        if ((li & 16) == 0) P[((r & 3) + 8 * (r >> 2) + 4 * h) * p.PS + bin] = p.mag_spec ? sqrtf(v) : v;
+      }
     }
   }
-  if (p.out_linear) {
-    float* dst = p.out_linear + ((long long)b * p.T + t0) * p.NB;
-    const int total = nvalid * p.NB;
-    for (int e = tid; e < total; e += 256) {
-      const int ff = e / p.NB;
-      const int k = e - ff * p.NB;
-      float v = (t0 + ff < flen) ? P[ff * p.PS + k] : 0.f;
-      if (p.lin_logging) v = logf(fmaxf(v, p.lin_clamp)) / p.lin_log_div;
-      dst[e] = v;
+  __syncthreads();
+  frontend_epilogue<FTF>(p, P, smem + p.off_O, b, t0, flen, tid, lane, wid);
+}
+
+// tables of the two-stage DFT; tpos holds LDS offsets (one pad word per hop when hop is even)
+__global__ void pfa400_tables_kernel(const float* window, int win_length, int hop, float* out) {
+  float* W25 = out;
+  float* W16c = W25 + 26 * 32;
+  float* W16r = W16c + 32 * 32;
+  int* tpos = (int*)(W16r + 16 * 32);
+  float* twin = (float*)(tpos + PFA_TAB);
+  const int padflag = (hop % 2 == 0) ? 1 : 0;
+  const int left = (400 - win_length) / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * 32; i += gridDim.x * blockDim.x) {
+    const int k = i >> 5, j = i & 31;
+    double s, c;
+    if (k < 26) {  // W25[n2][comp]
+      float v = 0.f;
+      if (k < 25 && j < 25) {
+        const int kk = j < 13 ? j : j - 12;
+        sincospi(2.0 * ((k * kk) % 25) / 25.0, &s, &c);
+        v = (float)(j < 13 ? c : -s);
+      }
+      W25[i] = v;
+    }
+    {  // W16c[(n1, ri)][(k1 | 16 + k1)]
+      const int n1 = k >> 1, ri = k & 1, k1 = j & 15;
+      sincospi(2.0 * ((n1 * k1) % 16) / 16.0, &s, &c);
+      W16c[i] = (float)(j < 16 ? (ri ? s : c) : (ri ? c : -s));
+    }
+    if (k < 16) {  // W16r[n1][(k1 | 16 + k1)]
+      const int k1 = j & 15;
+      sincospi(2.0 * ((k * k1) % 16) / 16.0, &s, &c);
+      W16r[i] = (float)(j < 16 ? c : -s);
+    }
+    if (i < PFA_TAB) {
+      const int n1 = i / 26, n2 = i % 26;
+      int pos = 0;
+      float w = 0.f;
+      if (n2 < 25) {
+        const int n = (25 * n1 + 16 * n2) % 400;
+        pos = n + (n / hop) * padflag;
+        w = (n >= left && n < left + win_length) ? window[n - left] : 0.f;
+      }
+      tpos[i] = pos;
+      twin[i] = w;
     }
   }
 }
@@ -255,18 +417,25 @@ __global__ void basis_kernel(const float* window, int win_length, int n_fft, int
 
 SC_API int sc_frontend_num_tiles(int n_fft) { return (n_fft / 2 + 1 + 15) / 16; }
 
-SC_API long long sc_frontend_basis_floats(int n_fft) {
+static long long direct_basis_floats(int n_fft) {
   const long long krows = (n_fft + 1) & ~1;
   return krows * sc_frontend_num_tiles(n_fft) * 32;
 }
 
-SC_API int sc_frontend_basis_init(const float* window, int win_length, int n_fft, float* basis, hipStream_t stream) {
+SC_API long long sc_frontend_basis_floats(int n_fft) { return direct_basis_floats(n_fft) + (n_fft == 400 ? PFA_FLOATS : 0); }
+
+SC_API int sc_frontend_basis_init(const float* window, int win_length, int n_fft, int hop, float* basis, hipStream_t stream) {
   SC_CHECK_ARG(window && basis, "sc_frontend_basis_init: null pointer");
   SC_CHECK_ARG(n_fft >= 2 && win_length >= 1 && win_length <= n_fft, "sc_frontend_basis_init: need 1 <= win_length <= n_fft, got %d, %d", win_length, n_fft);
   const int NT = sc_frontend_num_tiles(n_fft);
   const int krows = (n_fft + 1) & ~1;
   hipLaunchKernelGGL(basis_kernel, dim3(256), dim3(256), 0, stream, window, win_length, n_fft, krows, NT, n_fft / 2 + 1, basis);
   SC_LAUNCH_CHECK("basis_kernel");
+  if (n_fft == 400) {
+    SC_CHECK_ARG(hop >= 1, "sc_frontend_basis_init: hop must be positive");
+    hipLaunchKernelGGL(pfa400_tables_kernel, dim3(4), dim3(256), 0, stream, window, win_length, hop, basis + direct_basis_floats(n_fft));
+    SC_LAUNCH_CHECK("pfa400_tables_kernel");
+  }
   return SC_OK;
 }
 
@@ -325,6 +494,22 @@ SC_API int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, 
   const size_t smem = (size_t)(a.off_O + O_floats) * sizeof(float);
   SC_CHECK_ARG(smem <= 160 * 1024, "sc_frontend_logmel_fwd: n_fft=%d hop=%d needs %zu B of LDS (> 160 KiB)", n_fft, hop, smem);
 
+  if (n_fft == 400 && !getenv("SC_FRONTEND_DIRECT")) {
+    // two-stage 16 x 25 DFT: 32 frames per workgroup; Y (32 x 401) overlaps the sample image, P follows, O overlaps Y
+    a.pfa = basis + direct_basis_floats(n_fft);
+    const int count32 = 31 * hop + a.krows;
+    const int samples32 = count32 + count32 / hop + 8;
+    const int region0 = samples32 > 32 * PFA_YS ? samples32 : 32 * PFA_YS;
+    a.off_P = (region0 + 3) & ~3;
+    a.off_O = 0;
+    const size_t smem_pfa = (size_t)(a.off_P + 32 * a.PS) * sizeof(float);
+    if (smem_pfa <= 160 * 1024 && 32 * a.OS <= region0) {
+      SC_HIP(hipFuncSetAttribute((const void*)frontend_pfa400_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pfa));
+      hipLaunchKernelGGL(frontend_pfa400_kernel, dim3(sc_cdiv(T, 32), B), dim3(256), smem_pfa, stream, a);
+      SC_LAUNCH_CHECK("frontend_pfa400_kernel");
+      return SC_OK;
+    }
+  }
   dim3 grid(sc_cdiv(T, FTF), B);
   if (FT == 2) {
     SC_HIP(hipFuncSetAttribute((const void*)frontend_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

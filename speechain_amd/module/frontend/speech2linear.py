@@ -31,8 +31,8 @@ def _to_samples(value, sr: int) -> int:
 class StftPlan:
     """Device-resident windowed-DFT basis for (window, win_length, n_fft); built lazily per device."""
 
-    def __init__(self, window: str, win_length: int, n_fft: int):
-        self.window, self.win_length, self.n_fft = window, win_length, n_fft
+    def __init__(self, window: str, win_length: int, n_fft: int, hop: int):
+        self.window, self.win_length, self.n_fft, self.hop = window, win_length, n_fft, hop
         self._basis = {}
 
     def basis(self, device: torch.device) -> torch.Tensor:
@@ -40,7 +40,7 @@ class StftPlan:
         if key not in self._basis:
             win = getattr(torch, f"{self.window}_window")(self.win_length, dtype=torch.float32, device=device)
             basis = torch.empty(lib.value("sc_frontend_basis_floats", self.n_fft), dtype=torch.float32, device=device)
-            lib.call("sc_frontend_basis_init", ptr(win), self.win_length, self.n_fft, ptr(basis), stream())
+            lib.call("sc_frontend_basis_init", ptr(win), self.win_length, self.n_fft, self.hop, ptr(basis), stream())
             self._basis[key] = basis
         return self._basis[key]
 
@@ -114,7 +114,7 @@ class Speech2LinearSpec(Module):
                                 normalized=normalized, onesided=onesided, return_complex=True)
         self.mag_spec, self.return_energy = mag_spec, return_energy
         self.clamp, self.logging, self.log_base = clamp, logging, log_base
-        self._plan = StftPlan(window, win_length, n_fft)
+        self._plan = StftPlan(window, win_length, n_fft, hop_length)
 
     def _prepare(self, speech: torch.Tensor, speech_len: torch.Tensor):
         """Optional min-max pre-normalisation needs the pre-emphasised signal first (speech2linear.py:167-185);

@@ -30,9 +30,10 @@ def test_loader_binds_and_reports_errors():
     _lib.lib.load()
     assert _lib.lib.value("sc_version") >= 1
     assert _lib.lib.value("sc_frontend_num_tiles", 400) == 13
-    assert _lib.lib.value("sc_frontend_basis_floats", 400) == 400 * 13 * 32
+    assert _lib.lib.value("sc_frontend_basis_floats", 400) >= 400 * 13 * 32
+    assert _lib.lib.value("sc_frontend_basis_floats", 1024) == 1024 * 33 * 32
     with pytest.raises(RuntimeError, match="null pointer"):
-        _lib.lib.call("sc_frontend_basis_init", None, 400, 400, None, None)
+        _lib.lib.call("sc_frontend_basis_init", None, 400, 400, 160, None, None)
 
 
 def test_modules_refuse_cpu_tensors_and_keep_state_dict_keys():
