@@ -68,25 +68,25 @@ template <int FTF>
 __device__ __forceinline__ void stage_samples(const FrontendArgs& p, float* smem, int b, int t0, long long wlen, int tid) {
   const float* x = p.wave + (long long)b * p.wave_stride;
   const int count = (FTF - 1) * p.hop + p.krows;
-  const long long padded_len = (long long)p.T_w + 2LL * p.pad;
+  const int padded_len = p.T_w + 2 * p.pad;
+  const int base = t0 * p.hop - p.pad;  // sample index of the span's first element (32-bit: T_w < 2^31)
+  const int len = (int)(wlen < p.T_w ? wlen : p.T_w);
   const float negc = -p.preemph;
+  const float inv_hop = 1.f / (float)p.hop;
   for (int i = tid; i < count; i += 256) {
-    const long long j = (long long)t0 * p.hop + i;
+    int n = base + i;
+    const bool inside = n + p.pad < padded_len;
+    n = n < 0 ? -n : n;
+    n = n >= p.T_w ? 2 * (p.T_w - 1) - n : n;
     float v = 0.f;
-    if (j < padded_len) {
-      long long n = j - p.pad;
-      if (n < 0) n = -n;
-      else if (n >= p.T_w) n = 2LL * (p.T_w - 1) - n;
+    if (inside) {
       if (p.use_preemph) {
-        if (n < wlen) {
-          const float prev = n > 0 ? x[n - 1] : 0.f;
-          v = fmaf(negc, prev, x[n]);
-        }
+        if (n < len) v = fmaf(negc, n > 0 ? x[n - 1] : 0.f, x[n]);
       } else {
         v = x[n];
       }
     }
-    smem[i + (i / p.hop) * p.padflag] = v;
+    smem[i + (int)(((float)i + 0.5f) * inv_hop) * p.padflag] = v;  // + one pad word per completed hop
   }
 }
 
@@ -246,8 +246,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendArgs p) {
 // both as exact-f32 MFMA products with the (tiny) DFT matrices held in registers; 13 MFMAs per frame instead of the 81 of the
 // direct 400 x 402 product, and FFT-like (short) accumulation chains.  The 208 computed (k1, k2) values cover the 201 bins
 // after folding k > 200 to 400 - k.
-constexpr int PFA_TAB = 16 * 26;
-constexpr int PFA_FLOATS = 26 * 32 + 32 * 32 + 16 * 32 + 2 * PFA_TAB;
+constexpr int PFA_FLOATS = 26 * 32 + 32 * 32 + 16 * 32 + 400;
 constexpr int PFA_YS = 401;  // Y row stride per frame: 16 * 25 + 1 (odd: conflict-free frame-major reads)
 
 __global__ __launch_bounds__(256, 2) void frontend_pfa400_kernel(FrontendArgs p) {
@@ -265,15 +264,15 @@ __global__ __launch_bounds__(256, 2) void frontend_pfa400_kernel(FrontendArgs p)
   const int flen = (int)(flen_ll < 0 ? 0 : (flen_ll > p.T ? p.T : flen_ll));
 
   stage_samples<FTF>(p, smem, b, t0, wlen, tid);
-  __syncthreads();
 
   const float* W25 = p.pfa;
   const float* W16c = W25 + 26 * 32;
   const float* W16r = W16c + 32 * 32;
-  const int* tpos = (const int*)(W16r + 16 * 32);
-  const float* twin = (const float*)(tpos + PFA_TAB);
+  const float* gwin = W16r + 16 * 32;  // window, zero-padded to 400 samples
   float* Y = smem;              // overlaps the sample image (rewritten only after every wave finished stage 1)
   float* P = smem + p.off_P;
+  float* win = P + FTF * p.PS;  // 400-entry window table in LDS
+  for (int i = tid; i < 400; i += 256) win[i] = gwin[i];
 
   // ---- stage 1: wave w transforms n1 = 4w .. 4w+3 ----
   {
@@ -285,14 +284,20 @@ __global__ __launch_bounds__(256, 2) void frontend_pfa400_kernel(FrontendArgs p)
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    __syncthreads();  // samples and window table are staged
     const float* frow = smem + li * (p.hop + p.padflag);
+    const float inv_hop = 1.f / (float)p.hop;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int n1 = wid * 4 + u;
 #pragma unroll
       for (int s = 0; s < 13; ++s) {
-        const int idx = n1 * 26 + 2 * s + h;
-        const float a = twin[idx] * frow[tpos[idx]];
+        // n = (25 n1 + 16 n2) mod 400 with n2 = 2s + h; the padded k-step (n2 = 25) multiplies a zero basis row
+        int n = 25 * n1 + 16 * (2 * s + h);
+        n = n >= 400 ? n - 400 : n;
+        n = (2 * s + h) < 25 ? n : 0;
+        const int pos = n + (int)(((float)n + 0.5f) * inv_hop) * p.padflag;  // + one pad word per completed hop
+        const float a = win[n] * frow[pos];
         acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[s], acc[u], 0, 0, 0);
       }
     }
@@ -347,10 +352,10 @@ __global__ void pfa400_tables_kernel(const float* window, int win_length, int ho
   float* W25 = out;
   float* W16c = W25 + 26 * 32;
   float* W16r = W16c + 32 * 32;
-  int* tpos = (int*)(W16r + 16 * 32);
-  float* twin = (float*)(tpos + PFA_TAB);
-  const int padflag = (hop % 2 == 0) ? 1 : 0;
+  float* gwin = W16r + 16 * 32;
   const int left = (400 - win_length) / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 400; i += gridDim.x * blockDim.x)
+    gwin[i] = (i >= left && i < left + win_length) ? window[i - left] : 0.f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * 32; i += gridDim.x * blockDim.x) {
     const int k = i >> 5, j = i & 31;
     double s, c;
@@ -372,18 +377,6 @@ __global__ void pfa400_tables_kernel(const float* window, int win_length, int ho
       const int k1 = j & 15;
       sincospi(2.0 * ((k * k1) % 16) / 16.0, &s, &c);
       W16r[i] = (float)(j < 16 ? c : -s);
-    }
-    if (i < PFA_TAB) {
-      const int n1 = i / 26, n2 = i % 26;
-      int pos = 0;
-      float w = 0.f;
-      if (n2 < 25) {
-        const int n = (25 * n1 + 16 * n2) % 400;
-        pos = n + (n / hop) * padflag;
-        w = (n >= left && n < left + win_length) ? window[n - left] : 0.f;
-      }
-      tpos[i] = pos;
-      twin[i] = w;
     }
   }
 }
@@ -502,7 +495,8 @@ SC_API int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, 
     const int region0 = samples32 > 32 * PFA_YS ? samples32 : 32 * PFA_YS;
     a.off_P = (region0 + 3) & ~3;
     a.off_O = 0;
-    const size_t smem_pfa = (size_t)(a.off_P + 32 * a.PS) * sizeof(float);
+    a.PS = 201;  // exactly the 201 bins (odd stride: conflict-free frame-major reads)
+    const size_t smem_pfa = (size_t)(a.off_P + 32 * a.PS + 400) * sizeof(float);
     if (smem_pfa <= 160 * 1024 && 32 * a.OS <= region0) {
       SC_HIP(hipFuncSetAttribute((const void*)frontend_pfa400_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pfa));
       hipLaunchKernelGGL(frontend_pfa400_kernel, dim3(sc_cdiv(T, 32), B), dim3(256), smem_pfa, stream, a);
