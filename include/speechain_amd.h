@@ -42,6 +42,13 @@ long long sc_frontend_basis_floats(int n_fft);
  * (speech2linear.py:192-198). */
 int sc_frontend_basis_init(const float* window, int win_length, int n_fft, int hop, float* basis, hipStream_t stream);
 
+/* Band-packed image of the mel matrix `linear2mel.mel_fbanks.weight` (linear2mel.py:135-140): 16 weight slots per
+ * filter + per-filter first bin / width, sc_frontend_mel_image_floats(n_mels) floats on the device.  Built once per
+ * (matrix, device); replaces nothing in the reference (it is the layout the fused kernel consumes). */
+long long sc_frontend_mel_image_floats(int n_mels);
+int sc_frontend_mel_image_init(const float* melw, const int* band_lo, const int* band_hi, int n_mels, int n_bins,
+                               float* image, hipStream_t stream);
+
 /* wave (B, T_w) f32 with row stride wave_stride, wave_len (B,) -> any of
  *   out_feat   (B, T, n_mels)  mel filterbank output, clamp+log when `logging` (value = ln(max(x, clamp)) / log_div)
  *   out_energy (B, T)          sqrt(clamp(sum_f power, 1e-10)), zero beyond feat_len   (speech2linear.py:216-233)
@@ -50,13 +57,15 @@ int sc_frontend_basis_init(const float* window, int win_length, int n_fft, int h
  * T must equal (T_w + 2*pad - n_fft)/hop + 1 with pad = center ? n_fft/2 : 0.  Frames >= feat_len are computed from
  * an all-zero power spectrum exactly as the reference does (speech2linear.py:226-228).
  * melw is the reference's (n_mels, n_fft/2+1) buffer `linear2mel.mel_fbanks.weight`; band_lo/band_hi (n_mels,) int32
- * give for each mel row the half-open range of bins holding its non-zero weights. */
+ * give for each mel row the half-open range of bins holding its non-zero weights.  mel_image (nullable) is the
+ * band-packed copy of melw made by sc_frontend_mel_image_init; with it the n_fft = 400 kernel keeps the filter weights
+ * in LDS, without it (or when a filter is wider than 16 bins) it reads the dense matrix. */
 int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, int B, int T_w, long long wave_stride,
                            int use_preemph, float preemph, int n_fft, int hop, int center, const float* basis,
                            const float* melw, const int* band_lo, const int* band_hi, int n_mels, int mag_spec,
                            float clamp, int logging, float log_div, float* out_feat, float* out_energy,
                            float* out_linear, float lin_clamp, int lin_logging, float lin_log_div,
-                           long long* feat_len, int T, hipStream_t stream);
+                           long long* feat_len, int T, const float* mel_image, hipStream_t stream);
 
 /* Stand-alone mel filterbank + clamp/log over an (N, NB) spectrogram: LinearSpec2MelSpec.forward
  * (speechain/module/frontend/linear2mel.py:163-189) when it is called on its own. */

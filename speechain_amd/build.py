@@ -45,7 +45,7 @@ def _compile(src, force):
         # a kernel that spills to scratch (e.g. an accumulator array that stopped being unrolled) is a performance bug:
         # refuse to build it silently
         spills = [(k, int(n)) for k, n in _SCRATCH.findall(r.stderr) if int(n) > 0]
-        if spills:
+        if spills and not os.environ.get("SC_ALLOW_SCRATCH"):  # (the override is for instrumented debug builds only)
             os.remove(obj)
             raise RuntimeError(f"{src}: kernels using scratch memory: {spills}")
         other = [l for l in r.stderr.splitlines() if "warning:" in l or "error:" in l]

@@ -32,19 +32,25 @@ class LinearSpec2MelSpec(Module):
         self._bands = None
 
     def bands(self):
-        """(lo, hi) int32 device tensors of each filter's support; recomputed when the buffer is replaced or moved."""
+        """(lo, hi, image): int32 device tensors of each filter's support and the band-packed weight image; recomputed
+        when the buffer is replaced or moved."""
         w = self.mel_fbanks.weight
         key = (w.data_ptr(), w._version, str(w.device))
         if self._bands is None or self._bands[0] != key:
             lo, hi = mel_bands(w)
-            self._bands = (key, lo.contiguous(), hi.contiguous())
-        return self._bands[1], self._bands[2]
+            lo, hi = lo.contiguous(), hi.contiguous()
+            image = None
+            if w.is_cuda:  # band-packed copy the fused frontend kernel keeps in LDS
+                image = torch.empty(lib.value("sc_frontend_mel_image_floats", self.n_mels), dtype=torch.float32, device=w.device)
+                lib.call("sc_frontend_mel_image_init", ptr(w), ptr(lo), ptr(hi), self.n_mels, w.size(1), ptr(image), stream())
+            self._bands = (key, lo, hi, image)
+        return self._bands[1], self._bands[2], self._bands[3]
 
     def forward(self, feat: torch.Tensor, feat_len: torch.Tensor):
         require_gpu(feat, "LinearSpec2MelSpec")
         x = feat.float().contiguous()
         out = torch.empty(*x.shape[:-1], self.n_mels, dtype=torch.float32, device=x.device)
-        lo, hi = self.bands()
+        lo, hi, _ = self.bands()
         lib.call("sc_mel_log_fwd", ptr(x), x.numel() // x.size(-1), x.size(-1), ptr(self.mel_fbanks.weight), ptr(lo), ptr(hi),
                  self.n_mels, float(self.clamp), 1 if self.logging else 0,
                  1.0 if self.log_base is None else math.log(self.log_base), ptr(out), stream())

@@ -71,11 +71,11 @@ def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPl
     n_bins = n_fft // 2 + 1
     mel = lin = energy = None
     n_mels = 0
-    lo = hi = None
+    lo = hi = image = None
     if melw is not None:
         n_mels = melw.size(0)
         mel = torch.empty(B, T, n_mels, dtype=torch.float32, device=dev)
-        lo, hi = bands
+        lo, hi, image = bands if len(bands) == 3 else (*bands, None)
     if want_linear:
         lin = torch.empty(B, T, n_bins, dtype=torch.float32, device=dev)
     if want_energy:
@@ -86,7 +86,7 @@ def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPl
              ptr(plan.basis(dev)), ptr(melw), ptr(lo), ptr(hi), n_mels, 1 if mag_spec else 0, float(clamp),
              1 if logging else 0, 1.0 if log_base is None else math.log(log_base), ptr(mel), ptr(energy), ptr(lin),
              float(lin_clamp), 1 if lin_logging else 0, 1.0 if lin_log_base is None else math.log(lin_log_base),
-             ptr(feat_len), T, stream())
+             ptr(feat_len), T, ptr(image), stream())
     return mel, lin, energy, feat_len
 
 

@@ -143,6 +143,60 @@ def test_full_size_batch_vs_oracle():
             assert float((out[i, int(rlen[i]):] + 10.0).abs().max()) < 1e-5
 
 
+def _rand_batch(B, T_w, seed):
+    gen = torch.Generator().manual_seed(seed)
+    wave = torch.randn(B, T_w, generator=gen) * 0.1
+    lens = torch.randint(T_w // 2, T_w + 1, (B,), generator=gen)
+    lens[0] = T_w
+    for i in range(B):
+        wave[i, lens[i]:] = 0
+    return wave, lens
+
+
+@pytest.mark.parametrize("conf", [
+    dict(ASR, n_mels=10),                                    # filters wider than the 16 LDS slots: dense-matrix loop
+    dict(ASR, hop_length=200),                               # n_fft = 400 with a hop the kernel is not specialised for
+    dict(ASR, hop_length=150, preemphasis=None),             # hop % 4 != 0: element-wise sample placement
+    dict(ASR, n_mels=41, mel_scale="htk", log_base=None),   # odd filter count, natural log
+], ids=["wide", "hop200", "hop150", "odd41"])
+def test_two_stage_dft_kernel_variants_vs_oracle(conf):
+    wave, lens = _rand_batch(3, 23456, 11)
+    ref, rlen = R.speech2mel(wave, lens, **conf)
+    out, olen = _mod(conf)(wave.cuda(), lens.cuda())
+    assert torch.equal(olen.cpu(), rlen)
+    assert _err(out, ref) < LOGMEL_TOL
+
+
+def test_mel_image_and_dense_matrix_paths_agree():
+    """The band-packed LDS image (sc_frontend_mel_image_init) is only a layout: without it the kernel reads the dense
+    mel matrix and must produce the same log-mel (log via v_log_f32 in both, sums in a different order: 1e-5)."""
+    from speechain_amd.module.frontend.speech2linear import run_frontend
+
+    m = _mod(ASR)
+    wave, lens = _rand_batch(2, 40000, 5)
+    s2l, l2m = m.speech2linear, m.linear2mel
+    lo, hi, image = l2m.bands()
+    assert image is not None
+    kw = dict(plan=s2l._plan, hop=s2l.hop_length, center=True, preemphasis=0.97, mag_spec=False, want_linear=False,
+              melw=l2m.mel_fbanks.weight, clamp=l2m.clamp, logging=True, log_base=10.0)
+    a = run_frontend(wave.cuda(), lens.cuda(), bands=(lo, hi, image), **kw)[0]
+    b = run_frontend(wave.cuda(), lens.cuda(), bands=(lo, hi), **kw)[0]
+    assert float((a - b).abs().max()) < 1e-5
+
+
+def test_linear_energy_magnitude_outputs_n_fft_400():
+    """Speech2LinearSpec on the two-stage kernel: magnitude spectrogram + energy, vs the oracle."""
+    from speechain_amd.module.frontend.speech2linear import Speech2LinearSpec
+
+    conf = dict(sr=16000, hop_length=160, win_length=400, mag_spec=True, return_energy=True, logging=True)
+    wave, lens = _rand_batch(3, 20000, 9)
+    ref = R.speech2linear(wave, lens, preemph=0.97, **conf)
+    out = Speech2LinearSpec(preemphasis=0.97, **conf).cuda()(wave.cuda(), lens.cuda())
+    assert torch.equal(out[1].cpu(), ref[1])
+    assert _err(out[0], ref[0]) < LOGMEL_TOL
+    assert float(((out[2].cpu() - ref[2]).abs() / (ref[2].abs() + 1e-3)).max()) < 1e-3
+
+
 SPECAUG_CASES = dict(
     recipe=dict(freq_mask_width=15, freq_mask_num=4, time_mask_width=0.05, time_mask_num=5),
     default=dict(),
