@@ -55,7 +55,7 @@ class FrontendWorkload:
     # algorithmic HBM bytes of the dominant kernel (the fused frontend) per launch: read the waveform once, write the
     # log-mel once: 32*160000*4 + 32*1001*80*4
     alg_bytes = BATCH * SAMPLES * 4 + BATCH * 1001 * 80 * 4
-    dominant = "frontend_kernel"
+    dominant = "frontend_pfa400_kernel"
 
     def __init__(self, device, seed):
         from speechain_amd.module.augment.specaug import SpecAugment
@@ -217,6 +217,16 @@ class ASRTrainStepWorkload:
                         "steps replay hipGraphs): sum of 2*M*N*K*batch / sum of the event durations"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_frontend_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline_train(seconds: float):
     """The oracle's ASR step (frontend -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
     on a bounded sample: ~`seconds` of steps over 4 of the 32 utterances (same per-utterance shapes), scaled to utterances/s."""
@@ -332,8 +342,10 @@ def main():
             kms = wl.dominant_ms()
             achieved = wl.alg_bytes / (kms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes}
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(wl.dominant),
+                    "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes,
+                    "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
+                                    "(profiles/r01_frontend_pmc_traffic.json); bench.py cannot run the profiler on itself"}
         else:
             roof = wl.roofline()
         line = {

@@ -185,16 +185,17 @@ def test_mel_image_and_dense_matrix_paths_agree():
 
 
 def test_linear_energy_magnitude_outputs_n_fft_400():
-    """Speech2LinearSpec on the two-stage kernel: magnitude spectrogram + energy, vs the oracle."""
+    """Speech2LinearSpec on the two-stage kernel: magnitude spectrogram + energy, vs the oracle.  Compared in the linear
+    domain against the spectrum's scale (a near-cancelled bin has no meaningful log)."""
     from speechain_amd.module.frontend.speech2linear import Speech2LinearSpec
 
-    conf = dict(sr=16000, hop_length=160, win_length=400, mag_spec=True, return_energy=True, logging=True)
+    conf = dict(sr=16000, hop_length=160, win_length=400, mag_spec=True, return_energy=True, logging=False)
     wave, lens = _rand_batch(3, 20000, 9)
     ref = R.speech2linear(wave, lens, preemph=0.97, **conf)
     out = Speech2LinearSpec(preemphasis=0.97, **conf).cuda()(wave.cuda(), lens.cuda())
     assert torch.equal(out[1].cpu(), ref[1])
-    assert _err(out[0], ref[0]) < LOGMEL_TOL
-    assert float(((out[2].cpu() - ref[2]).abs() / (ref[2].abs() + 1e-3)).max()) < 1e-3
+    assert _err(out[0], ref[0]) < 1e-5 * float(ref[0].abs().max())
+    assert float(((out[2].cpu() - ref[2]).abs() / (ref[2].abs() + 1e-3)).max()) < 1e-4
 
 
 SPECAUG_CASES = dict(
