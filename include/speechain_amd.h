@@ -104,10 +104,14 @@ int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, in
             int accumulate, hipStream_t stream);
 
 /* Split-K form for wgrad-shaped products (small M x N, long contraction K), bf16 operands, f32 output with ldc == N:
- * C (+)= alpha * opA opB^T.  `workspace` holds splitk partial M x N tiles that a second deterministic kernel sums. */
+ * C (+)= alpha * opA opB^T.  `workspace` holds splitk partial M x N tiles that a second deterministic kernel sums.
+ * colsum (nullable, needs ta): colsum[m] (+)= sum_k A[k][m], the column sums of the transposed A over the contraction --
+ * for dW = dz^T x this is the bias gradient of the same nn.Linear (autograd of attention.py:72-79, feed_forward.py:93-101),
+ * taken from the tiles the product streams anyway and reduced by the same second kernel (fixed order: deterministic). */
 long long sc_gemm_splitk_workspace(int M, int N, int splitk);
 int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M, int N, int K, long long lda, long long ldb,
-                   float alpha, int splitk, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream);
+                   float alpha, int splitk, int accumulate, float* colsum, void* workspace, long long ws_bytes,
+                   hipStream_t stream);
 
 /* nn.LayerNorm over the last dim D of an (R, D) matrix (encoder.py:97-98,291-292; decoder.py:90-92; pos_enc.py:94-95);
  * mean/rstd (R,) are saved for the backward pass (may be null).  Backward returns dx and the parameter gradients;

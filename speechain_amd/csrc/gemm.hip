@@ -49,6 +49,7 @@ struct GemmArgs {
   int c_vec, c_vec32;  // vector accesses allowed for C/aux/pre_out in the compute dtype / for an f32 C
   int splitk;          // > 1: blockIdx.z is a K slice of ksplit_len, raw f32 partial tiles go to slab z of C
   int ksplit_len;
+  float* colsum_part;  // split-K with a transposed A only: per-slice column sums of A over the contraction, (slices, M) f32, or null
 };
 
 template <typename T> struct Elem;
@@ -535,6 +536,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Column sums of A over the contraction (the bias gradient of a wgrad product: A = dz read transposed).  The A tile
+  // passes through registers on its way to LDS and thread t always holds the same 8 columns m0 + (t & 15) * 8 .. + 7
+  // (rows (t >> 4) and (t >> 4) + 16 of each K tile), so the workgroups of the first N tile add them up on the way.
+  const bool csum = TA && p.colsum_part != nullptr && n0 == 0;
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#define SC_CSUM(RA)                                                                     \
+  do {                                                                                  \
+    if (csum) {                                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                \
+        const unsigned w_[4] = {RA[i_].x, RA[i_].y, RA[i_].z, RA[i_].w};                \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                              \
+          cs[2 * e_] += __uint_as_float(w_[e_] << 16);                                  \
+          cs[2 * e_ + 1] += __uint_as_float(w_[e_] & 0xffff0000u);                      \
+        }                                                                               \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+
   // K range of this workgroup (split-K: slice z of the contraction)
   const int kbeg = p.splitk > 1 ? z * p.ksplit_len : 0;
   const int kend = p.splitk > 1 ? min(p.K, kbeg + p.ksplit_len) : p.K;
@@ -572,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     if ((T) + 1 < nk) {                                                                 \
       store_tile16<TA>(As + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_A);                 \
       store_tile16<TB>(Bs + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_B);                 \
+      SC_CSUM(RNEXT_A);                                                                 \
     }                                                                                   \
     __syncthreads();                                                                    \
   } while (0)
@@ -596,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     SC_COMPUTE((T) & 1);                                                                \
     store_tile16<TA>(As + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_A);                   \
     store_tile16<TB>(Bs + (((T) + 1) & 1) * BM * LD16, tid, RNEXT_B);                   \
+    SC_CSUM(RNEXT_A);                                                                   \
     __syncthreads();                                                                    \
   } while (0)
 
@@ -607,6 +630,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     SC_LOAD_FAST(ra2, rb2, 2);
     store_tile16<TA>(As, tid, ra0);
     store_tile16<TB>(Bs, tid, rb0);
+    SC_CSUM(ra0);
     __syncthreads();
     for (; t + 6 <= nfull; t += 3) {  // steps t, t+1, t+2 load tiles t+3, t+4, t+5 (all full)
       SC_STEP_FAST(t, ra0, rb0, ra1, rb1);
@@ -621,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     if (nk > 0) {
       store_tile16<TA>(As, tid, ra0);
       store_tile16<TB>(Bs, tid, rb0);
+      SC_CSUM(ra0);
     }
     __syncthreads();
   }
@@ -634,6 +659,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #undef SC_LOAD
 #undef SC_COMPUTE
 #undef SC_STEP
+#undef SC_CSUM
+
+  if (csum) {  // 16 row-groups x 128 columns through LDS (the tiles are dead: the loop ended on a barrier)
+    float* red = (float*)smem;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < p.M) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += red[g * 128 + tid];
+      p.colsum_part[(long long)z * p.M + m0 + tid] = v;
+    }
+    __syncthreads();  // the epilogue reuses smem as its staging tile
+  }
 
   if (p.splitk > 1) {  // raw partial tile -> slab z (f32, no epilogue); the reduce kernel finishes the job
     float* stage = (float*)smem + wid * 32 * STG_LD;
@@ -929,8 +969,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
   epilogue_wave<float, 2>(p, smem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
-// out[i] (+)= sum_s slab[s][i]   (deterministic split-K second stage)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int S, long long n, float* out, int accumulate) {
+// out[i] (+)= sum_s slab[s][i]   (deterministic split-K second stage); optionally the same for a second, short segment
+// (the per-slice column sums: out2[j] (+)= sum_s part2[s][j], j < n2)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int S, long long n, float* out, int accumulate,
+                                                            const float* part2, int n2, float* out2) {
+  if (out2 != nullptr) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n2; j += gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < S; ++k) s += part2[(long long)k * n2 + j];
+      out2[j] = accumulate ? out2[j] + s : s;
+    }
+  }
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -1014,10 +1063,15 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
 // Split-K product for wgrad-shaped problems (small M x N output, long contraction): C (f32, M x N, ldc == N)
 // (+)= alpha * opA opB^T with the contraction cut into `splitk` slices whose partial tiles go to `workspace`
 // (splitk * M * N floats) and are summed by a second, deterministic kernel.  bf16 operands only.
-SC_API long long sc_gemm_splitk_workspace(int M, int N, int splitk) { return (long long)splitk * M * N * (long long)sizeof(float); }
+// (splitk * M * N slab floats, then splitk * M floats for the optional column sums)
+SC_API long long sc_gemm_splitk_workspace(int M, int N, int splitk) {
+  return ((long long)splitk * M * N + (long long)splitk * M) * (long long)sizeof(float);
+}
 
 SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M, int N, int K, long long lda, long long ldb,
-                          float alpha, int splitk, int accumulate, void* workspace, long long ws_bytes, hipStream_t stream) {
+                          float alpha, int splitk, int accumulate, float* colsum, void* workspace, long long ws_bytes,
+                          hipStream_t stream) {
+  SC_CHECK_ARG(colsum == nullptr || ta, "sc_gemm_splitk: colsum needs a transposed A (its columns are the rows of C)");
   SC_CHECK_ARG(A && B && C && workspace, "sc_gemm_splitk: null pointer");
   SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && splitk >= 2 && splitk <= 64, "sc_gemm_splitk: bad sizes");
   SC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? N : K), "sc_gemm_splitk: leading dimension too small");
@@ -1033,6 +1087,8 @@ SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C
   a.ksplit_len = ((K + splitk - 1) / splitk + BK16 - 1) / BK16 * BK16;
   const int slices = (K + a.ksplit_len - 1) / a.ksplit_len;
   a.splitk = slices > 1 ? slices : 2;  // keep the split-K code path even if rounding left a single slice
+  float* part2 = (float*)workspace + (long long)splitk * M * N;
+  a.colsum_part = colsum ? part2 : nullptr;
   int rc;
   if (!ta && !tb) rc = launch(gemm_bf16_kernel<false, false>, a, slices, stream, "gemm_bf16<NT> split-K");
   else if (!ta && tb) rc = launch(gemm_bf16_kernel<false, true>, a, slices, stream, "gemm_bf16<NN> split-K");
@@ -1043,7 +1099,8 @@ SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, slices, n, C, accumulate);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, slices, n, C, accumulate,
+                     (const float*)part2, M, colsum);
   SC_LAUNCH_CHECK("splitk_reduce_kernel");
   return SC_OK;
 }

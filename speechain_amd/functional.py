@@ -333,23 +333,31 @@ class _Side:
             self.main.wait_stream(self.side)
 
 
-def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.Tensor] = ()) -> torch.Tensor:
+def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.Tensor] = (), bias: bool = False,
+          bias_params: Sequence[torch.Tensor] = ()):
     """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K), written into the registered gradient slots of `params` when they
     have adjacent ones.  The output is small and the contraction long, so in bf16 mode the contraction is split across
-    workgroups (sc_gemm_splitk) to fill the chip."""
+    workgroups (sc_gemm_splitk) to fill the chip.  With `bias` the bias gradient db (N,) = column sums of dz comes back
+    too: the split-K kernel takes it from the dz tiles it streams anyway, otherwise a separate column-sum launch does."""
     M, N = dz.shape
     K = x2.size(1)
     sink = GradSinks.take(params) if params else None
     dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     splitk = min(16, max(1, 512 // tiles), max(1, M // 256))
+    db = None
     if code == BF16 and splitk >= 2:
+        if bias:
+            bsink = GradSinks.take(bias_params) if bias_params else None
+            db = bsink if bsink is not None else torch.empty(N, dtype=torch.float32, device=dz.device)
         ws = torch.empty(lib.value("sc_gemm_splitk_workspace", N, K, splitk), dtype=torch.uint8, device=dz.device)
-        lib.call("sc_gemm_splitk", 1, 1, _p(dz), _p(x2), _p(dW), N, K, M, dz.stride(0), x2.stride(0), 1.0, splitk, 0, _p(ws),
-                 ws.numel(), stream())
+        lib.call("sc_gemm_splitk", 1, 1, _p(dz), _p(x2), _p(dW), N, K, M, dz.stride(0), x2.stride(0), 1.0, splitk, 0, _p(db),
+                 _p(ws), ws.numel(), stream())
     else:
         gemm(code, _p(dz), _p(x2), _p(dW), N, K, M, dz.stride(0), x2.stride(0), K, ta=1, tb=1, out_f32=True)
-    return dW
+        if bias:
+            db = _colsum(dz, bias_params)
+    return (dW, db) if bias else dW
 
 
 def dgrad(code: int, dz: torch.Tensor, ws: Sequence[torch.Tensor], out: torch.Tensor, **epi):
@@ -429,11 +437,12 @@ class _Linear(torch.autograd.Function):
         W = weights.fused(ws, x2.dtype)
         side = _Side(x2)
         with side:  # parameter gradients next to the data gradient
-            dW = wgrad(code, dz, x2, ws)  # dW = dz^T x
+            # dW = dz^T x, and db = column sums of dz out of the same launch
+            dW, db = wgrad(code, dz, x2, ws, bias=True, bias_params=ctx.bias_params if all(has_b) else ()) if any(has_b) \
+                else (wgrad(code, dz, x2, ws), None)
             dws = list(dW.split(rows, dim=0))
             dbs = [None] * len(rows)
             if any(has_b):
-                db = _colsum(dz, ctx.bias_params if all(has_b) else ())
                 dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
         dx = None
         if ctx.needs_input_grad[0]:
@@ -485,8 +494,7 @@ class _LinearAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dgrad(code, dpre, [w], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
-        dW = wgrad(code, dpre, x2, [w])
-        db = _colsum(dpre, ctx.bias_params) if has_b else None
+        dW, db = wgrad(code, dpre, x2, [w], bias=True, bias_params=ctx.bias_params) if has_b else (wgrad(code, dpre, x2, [w]), None)
         return dx, dW, db, None, None
 
 
@@ -544,14 +552,14 @@ class _FFN(torch.autograd.Function):
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
         side = _Side(x2)
         with side:
-            dW2 = wgrad(code, dz, h, [w2])
-            db2 = _colsum(dz, ctx.bias_params[1]) if has_b2 else None
+            dW2, db2 = wgrad(code, dz, h, [w2], bias=True, bias_params=ctx.bias_params[1]) if has_b2 \
+                else (wgrad(code, dz, h, [w2]), None)
         # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
         dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), act=act, aux=_p(h_pre), ldaux=Fd,
                      aux_mode=2, drop=(p_h, s1, o1))
         with side:
-            dW1 = wgrad(code, dpre, x2, [w1])
-            db1 = _colsum(dpre, ctx.bias_params[0]) if has_b1 else None
+            dW1, db1 = wgrad(code, dpre, x2, [w1], bias=True, bias_params=ctx.bias_params[0]) if has_b1 \
+                else (wgrad(code, dpre, x2, [w1]), None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dgrad(code, dpre, [w1], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)

@@ -123,3 +123,21 @@ def test_wgrad_split_k(M, N, K):
         assert dW.dtype == torch.float32 and dW.shape == (N, K)
         tol = dict(atol=2e-3 * math.sqrt(M / 64), rtol=1e-4) if dtype == torch.float32 else dict(atol=0.05 * math.sqrt(M / 64), rtol=2e-2)
         assert torch.allclose(dW.double(), ref, **tol), float((dW.double() - ref).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(7968, 2048, 512), (7968, 512, 2048), (2016, 1536, 512), (999, 130, 70), (300, 5000, 512), (64, 96, 40)])
+def test_wgrad_bias_gradient_from_the_same_launch(M, N, K):
+    """db = column sums of dz, taken by the split-K wgrad kernel from the dz tiles it streams (bf16) or by the separate
+    column-sum launch (f32 / no split): against the fp64 sum of the same values.  Only the order of an f32 summation
+    differs, so the bound is M * 2^-23 of the column's absolute sum; dW must be unchanged by asking for db."""
+    for dtype in (torch.bfloat16, torch.float32):
+        dz, x = _mk((M, N), dtype, 30), _mk((M, K), dtype, 31)
+        dW, db = Fn.wgrad(Fn.dcode(dz), dz, x, bias=True)
+        assert db.dtype == torch.float32 and db.shape == (N,)
+        ref = dz.double().sum(0)
+        bound = dz.double().abs().sum(0) * M * 2.0 ** -23 + 1e-6
+        err = (db.double() - ref).abs()
+        assert bool((err <= bound).all()), float((err / bound).max())
+        assert torch.equal(dW, Fn.wgrad(Fn.dcode(dz), dz, x))
+        # deterministic: same launch twice, same bits
+        assert torch.equal(db, Fn.wgrad(Fn.dcode(dz), dz, x, bias=True)[1])
