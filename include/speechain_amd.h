@@ -171,14 +171,15 @@ int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, 
 
 /* CTC negative log-likelihood per utterance and its gradient w.r.t. the logits (speechain/criterion/ctc.py:48-65 =
  * log_softmax + F.ctc_loss(reduction='none')).  logits (B, Tmax, V); lse (B, Tmax) from sc_row_lse; tgt holds label
- * ids with row stride tgt_stride; alpha is a (B, Tmax, Smax) float workspace, Smax >= 2*max(tgt_len)+1.
+ * ids with row stride tgt_stride; alpha (forward, kept) and beta (backward scratch) are (B, Tmax, Smax) float workspaces,
+ * Smax >= 2*max(tgt_len)+1; V <= 65536.
  * nll may be +inf (infeasible alignment); the caller applies zero_infinity through gscale[b] (= upstream/B, or 0). */
 int sc_ctc_fwd(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
                long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, float* alpha,
                float* nll, hipStream_t stream);
 int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
                long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, const float* alpha,
-               const float* nll, const float* gscale, void* grad, hipStream_t stream);
+               const float* nll, const float* gscale, float* beta, void* grad, hipStream_t stream);
 
 /* dtype casts (0 = f32, 1 = bf16) and the transposed cast out[c][r] = in[r][c] of an (R, C) f32 matrix. */
 int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);

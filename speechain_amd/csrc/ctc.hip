@@ -3,12 +3,16 @@
 //
 // The (B, T, V) log-softmax is never materialised: a row-wise logsumexp (sc_row_lse) gives lse[b][t] and the
 // recursions gather logit[b][t][label] - lse[b][t] for the <= 2L+1 extended labels only.
-//   forward : one workgroup per utterance, alpha_t(s) in LDS (double buffered), one barrier per frame; all alphas are
-//             kept in a (B, T, S) f32 workspace for the backward pass; nll[b] = -logsumexp(alpha_T(S-1), alpha_T(S-2))
-//   backward: a dense pass writes g_b * softmax (zero beyond the utterance length); then one workgroup per utterance
-//             runs the beta recursion and overwrites the label columns with
-//               g_b * (softmax[t][v] - exp(logsumexp_{s: l'_s = v}(alpha_t(s) + beta_t(s)) - lp[t][v] + nll_b))
-//             (beta includes the emission at t, as in torch's kernels).
+//   forward : one workgroup per utterance, alpha_t(s) in LDS (double buffered), ONE barrier per frame; the emission
+//             log-probabilities of the next frames are gathered from HBM two frames ahead (they do not depend on the
+//             recursion), so a frame costs an LDS round trip instead of an HBM one.  All alphas are kept in a (B, T, S)
+//             f32 workspace; nll[b] = -logsumexp(alpha_T(S-1), alpha_T(S-2)).
+//   backward: the same recursion run backwards stores beta_t(s) (including the emission at t, as in torch's kernels) in a
+//             second (B, T, S) workspace; then ONE WORKGROUP PER FRAME (B x T of them, fully parallel) writes
+//               grad[t][v] = g_b * softmax[t][v]                                                       v not a label
+//               grad[t][v] = g_b * (softmax[t][v] - exp(logsumexp_{s: l'_s = v}(alpha_t(s) + beta_t(s)) - lp[t][v] + nll_b))
+//             and zeros beyond the utterance length.  (Before: the label columns were patched inside the sequential
+//             beta kernel -- two tree reductions, ~20 barriers and un-prefetched gathers per frame, 735 us per step.)
 #include "sc_common.h"
 
 namespace {
@@ -48,7 +52,21 @@ struct CtcArgs {
   float* nll;               // (B,) raw negative log-likelihood (may be +inf)
   const float* gscale;      // (B,) backward only
   void* grad;               // (B, Tmax, V) backward only
+  float* beta;              // (B, Tmax, Smax) backward only
 };
+
+constexpr int kSPT = kMaxS / 256;  // extended-label positions per thread
+
+// emission log-probabilities lp[t][ext[s]] = logit - lse of frame t for this thread's positions s = tid + 256 i
+template <typename T>
+__device__ __forceinline__ void ctc_gather(const CtcArgs& p, long long lbase, int b, int t, const int* ext, int S, int tid, float (&lp)[kSPT]) {
+  const float lt = p.lse[(long long)b * p.Tmax + t];
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    const int s = tid + 256 * i;
+    lp[i] = s < S ? Lg<T>::ld(p.logits, lbase + (long long)t * p.V + ext[s]) - lt : -INFINITY;
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
@@ -66,28 +84,43 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
   }
   const long long lbase = (long long)b * p.Tmax * p.V;
   float* abase = p.alpha + (long long)b * p.Tmax * p.Smax;
-  {
-    const float l0 = p.lse[(long long)b * p.Tmax];
-    for (int s = tid; s < S; s += 256) {
-      float a = -INFINITY;
-      if (s < 2) a = Lg<T>::ld(p.logits, lbase + ext[s]) - l0;
+  bool skip2[kSPT];  // the s-2 -> s transition exists (odd s, different label)
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    const int s = tid + 256 * i;
+    skip2[i] = s < S && s >= 2 && (s & 1) && ext[s] != ext[s - 2];
+  }
+  float lp0[kSPT], lp1[kSPT], lp2[kSPT];
+  ctc_gather<T>(p, lbase, b, 0, ext, S, tid, lp0);
+  if (Tb > 1) ctc_gather<T>(p, lbase, b, 1, ext, S, tid, lp1);
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    const int s = tid + 256 * i;
+    if (s < S) {
+      const float a = s < 2 ? lp0[i] : -INFINITY;
       buf[0][s] = a;
       abase[s] = a;
     }
   }
   __syncthreads();
   for (int t = 1; t < Tb; ++t) {
+    if (t + 1 < Tb) ctc_gather<T>(p, lbase, b, t + 1, ext, S, tid, lp2);  // in flight across this frame's barrier
     const float* prev = buf[(t - 1) & 1];
     float* cur = buf[t & 1];
-    const float lt = p.lse[(long long)b * p.Tmax + t];
-    for (int s = tid; s < S; s += 256) {
-      const float a0 = prev[s];
-      const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-      const float a2 = (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) ? prev[s - 2] : -INFINITY;
-      const float v = lse3(a0, a1, a2) + (Lg<T>::ld(p.logits, lbase + (long long)t * p.V + ext[s]) - lt);
-      cur[s] = v;
-      abase[(long long)t * p.Smax + s] = v;
+#pragma unroll
+    for (int i = 0; i < kSPT; ++i) {
+      const int s = tid + 256 * i;
+      if (s < S) {
+        const float a0 = prev[s];
+        const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+        const float a2 = skip2[i] ? prev[s - 2] : -INFINITY;
+        const float v = lse3(a0, a1, a2) + lp1[i];
+        cur[s] = v;
+        abase[(long long)t * p.Smax + s] = v;
+      }
     }
+#pragma unroll
+    for (int i = 0; i < kSPT; ++i) lp1[i] = lp2[i];
     __syncthreads();
   }
   if (tid == 0) {
@@ -97,106 +130,128 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
   }
 }
 
-// grad[b][t][v] = gscale[b] * softmax(logits[b][t])[v] for t < in_len[b], else 0
+// beta_t(s) (with the emission at t) for t = Tb-1 .. 0 into p.beta (B, Tmax, Smax); same structure as the alpha kernel
 template <typename T>
-__global__ __launch_bounds__(256) void ctc_dense_grad_kernel(CtcArgs p) {
-  const long long row = blockIdx.x;
-  const int b = (int)(row / p.Tmax), t = (int)(row - (long long)b * p.Tmax);
-  const float g = (t < p.in_len[b]) ? p.gscale[b] : 0.f;
-  const long long base = row * p.V;
-  const float l = p.lse[row];
-  for (int v = threadIdx.x; v < p.V; v += 256) Lg<T>::st(p.grad, base + v, g != 0.f ? g * expf(Lg<T>::ld(p.logits, base + v) - l) : 0.f);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void ctc_beta_grad_kernel(CtcArgs p) {
+__global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
   __shared__ int ext[kMaxS];
-  __shared__ int nxt[kMaxS];      // next later position carrying the same (non-blank) label, or -1
-  __shared__ unsigned char lead[kMaxS];
   __shared__ float buf[2][kMaxS];
-  __shared__ float ab[kMaxS];
-  __shared__ float red[256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const float g = p.gscale[b];
-  if (g == 0.f) return;  // infinite loss (zero_infinity) or zero upstream gradient: the dense pass already wrote zeros
+  if (p.gscale[b] == 0.f) return;  // infinite loss (zero_infinity) or zero upstream gradient: the gradient is all zeros
   const int L = (int)p.tgt_len[b];
   const int S = 2 * L + 1;
   const int Tb = (int)min((long long)p.Tmax, p.in_len[b]);
   if (Tb <= 0) return;
   for (int s = tid; s < S; s += 256) ext[s] = (s & 1) ? (int)p.tgt[b * p.tgt_stride + (s >> 1)] : p.blank;
   __syncthreads();
-  for (int s = tid; s < S; s += 256) {
-    int n = -1;
-    unsigned char first = 1;
-    if (s & 1) {
-      for (int s2 = s + 2; s2 < S; s2 += 2)
-        if (ext[s2] == ext[s]) { n = s2; break; }
-      for (int s2 = 1; s2 < s; s2 += 2)
-        if (ext[s2] == ext[s]) { first = 0; break; }
-    }
-    nxt[s] = n;
-    lead[s] = first;
-  }
-  const float nll = p.nll[b];
   const long long lbase = (long long)b * p.Tmax * p.V;
-  const float* abase = p.alpha + (long long)b * p.Tmax * p.Smax;
+  float* bbase = p.beta + (long long)b * p.Tmax * p.Smax;
+  bool skip2[kSPT];  // the s -> s+2 transition exists
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    const int s = tid + 256 * i;
+    skip2[i] = s + 2 < S && (s & 1) && ext[s] != ext[s + 2];
+  }
+  float lp0[kSPT], lp1[kSPT], lp2[kSPT];
+  ctc_gather<T>(p, lbase, b, Tb - 1, ext, S, tid, lp0);
+  if (Tb > 1) ctc_gather<T>(p, lbase, b, Tb - 2, ext, S, tid, lp1);
+#pragma unroll
+  for (int i = 0; i < kSPT; ++i) {
+    const int s = tid + 256 * i;
+    if (s < S) {
+      const float v = s >= S - 2 ? lp0[i] : -INFINITY;
+      buf[(Tb - 1) & 1][s] = v;
+      bbase[(long long)(Tb - 1) * p.Smax + s] = v;
+    }
+  }
   __syncthreads();
-  for (int t = Tb - 1; t >= 0; --t) {
-    float* cur = buf[t & 1];
+  for (int t = Tb - 2; t >= 0; --t) {
+    if (t >= 1) ctc_gather<T>(p, lbase, b, t - 1, ext, S, tid, lp2);
     const float* nextb = buf[(t + 1) & 1];
-    const float lt = p.lse[(long long)b * p.Tmax + t];
-    float blank_max = -INFINITY;
-    for (int s = tid; s < S; s += 256) {
-      const float lp = Lg<T>::ld(p.logits, lbase + (long long)t * p.V + ext[s]) - lt;
-      float v;
-      if (t == Tb - 1) {
-        v = (s >= S - 2) ? lp : -INFINITY;
-      } else {
+    float* cur = buf[t & 1];
+#pragma unroll
+    for (int i = 0; i < kSPT; ++i) {
+      const int s = tid + 256 * i;
+      if (s < S) {
         const float b0 = nextb[s];
-        const float b1 = (s + 1 < S) ? nextb[s + 1] : -INFINITY;
-        const float b2 = (s + 2 < S && (s & 1) && ext[s] != ext[s + 2]) ? nextb[s + 2] : -INFINITY;
-        v = lse3(b0, b1, b2) + lp;
-      }
-      cur[s] = v;
-      const float x = abase[(long long)t * p.Smax + s] + v;
-      ab[s] = x;
-      if (!(s & 1)) blank_max = fmaxf(blank_max, x);
-    }
-    // logsumexp over the blank positions (even s): workgroup max, then sum of exp
-    red[tid] = blank_max;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-      __syncthreads();
-    }
-    const float bm = red[0];
-    __syncthreads();
-    float bs = 0.f;
-    if (bm != -INFINITY)
-      for (int s = tid * 2; s < S; s += 512) bs += expf(ab[s] - bm);
-    red[tid] = bs;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    const long long gbase = lbase + (long long)t * p.V;
-    if (tid == 0) {
-      const float lpb = Lg<T>::ld(p.logits, gbase + p.blank) - lt;
-      const float lc = (bm == -INFINITY) ? -INFINITY : bm + logf(red[0]);
-      Lg<T>::st(p.grad, gbase + p.blank, g * (expf(lpb) - expf(lc - lpb + nll)));
-    }
-    // non-blank labels: the first occurrence gathers every later occurrence of the same label
-    for (int s = tid; s < S; s += 256) {
-      if ((s & 1) && lead[s]) {
-        float lc = ab[s];
-        for (int s2 = nxt[s]; s2 >= 0; s2 = nxt[s2]) lc = lse2(lc, ab[s2]);
-        const float lpv = Lg<T>::ld(p.logits, gbase + ext[s]) - lt;
-        Lg<T>::st(p.grad, gbase + ext[s], g * (expf(lpv) - expf(lc - lpv + nll)));
+        const float b1 = s + 1 < S ? nextb[s + 1] : -INFINITY;
+        const float b2 = skip2[i] ? nextb[s + 2] : -INFINITY;
+        const float v = lse3(b0, b1, b2) + lp1[i];
+        cur[s] = v;
+        bbase[(long long)t * p.Smax + s] = v;
       }
     }
+#pragma unroll
+    for (int i = 0; i < kSPT; ++i) lp1[i] = lp2[i];
     __syncthreads();
   }
+}
+
+// One workgroup per frame (b, t): the whole gradient row.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs p) {
+  __shared__ int ext[kMaxS];
+  __shared__ float ab[kMaxS];
+  __shared__ unsigned islabel[(1 << 16) / 32];  // bitmap over the vocabulary (V <= 65536: checked on the host)
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const int b = (int)(row / p.Tmax), t = (int)(row - (long long)b * p.Tmax);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float g = (t < p.in_len[b]) ? p.gscale[b] : 0.f;
+  const long long base = row * p.V;
+  if (g == 0.f) {
+    for (int v = tid; v < p.V; v += 256) Lg<T>::st(p.grad, base + v, 0.f);
+    return;
+  }
+  const int L = (int)p.tgt_len[b];
+  const int S = 2 * L + 1;
+  const float lt = p.lse[row];
+  const float nll = p.nll[b];
+  for (int w = tid; w < (p.V + 31) / 32; w += 256) islabel[w] = 0u;
+  const float* arow = p.alpha + ((long long)b * p.Tmax + t) * p.Smax;
+  const float* brow = p.beta + ((long long)b * p.Tmax + t) * p.Smax;
+  float blank_max = -INFINITY;
+  for (int s = tid; s < S; s += 256) {
+    ext[s] = (s & 1) ? (int)p.tgt[b * p.tgt_stride + (s >> 1)] : p.blank;
+    const float x = arow[s] + brow[s];
+    ab[s] = x;
+    if (!(s & 1)) blank_max = fmaxf(blank_max, x);
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256) atomicOr(&islabel[ext[s] >> 5], 1u << (ext[s] & 31));
+  // logsumexp over the blank positions (even s)
+  blank_max = sc_wave_max(blank_max);
+  if (lane == 0) red[wid] = blank_max;
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float bs = 0.f;
+  if (bm != -INFINITY)
+    for (int s = tid * 2; s < S; s += 512) bs += expf(ab[s] - bm);
+  bs = sc_wave_sum(bs);
+  if (lane == 0) red[4 + wid] = bs;
+  __syncthreads();
+  if (tid == 0) {
+    const float lpb = Lg<T>::ld(p.logits, base + p.blank) - lt;
+    const float lc = (bm == -INFINITY) ? -INFINITY : bm + logf(red[4] + red[5] + red[6] + red[7]);
+    Lg<T>::st(p.grad, base + p.blank, g * (expf(lpb) - expf(lc - lpb + nll)));
+  }
+  // non-blank labels: the first occurrence gathers every later occurrence of the same label
+  for (int s = tid; s < S; s += 256) {
+    if (s & 1) {
+      bool first = true;
+      for (int s2 = 1; s2 < s; s2 += 2)
+        if (ext[s2] == ext[s]) { first = false; break; }
+      if (first) {
+        float lc = ab[s];
+        for (int s2 = s + 2; s2 < S; s2 += 2)
+          if (ext[s2] == ext[s]) lc = lse2(lc, ab[s2]);
+        const float lpv = Lg<T>::ld(p.logits, base + ext[s]) - lt;
+        Lg<T>::st(p.grad, base + ext[s], g * (expf(lpv) - expf(lc - lpv + nll)));
+      }
+    }
+  }
+  // every other class: g * softmax
+  for (int v = tid; v < p.V; v += 256)
+    if (!((islabel[v >> 5] >> (v & 31)) & 1u)) Lg<T>::st(p.grad, base + v, g * expf(Lg<T>::ld(p.logits, base + v) - lt));
 }
 
 }  // namespace
@@ -216,16 +271,17 @@ SC_API int sc_ctc_fwd(int dtype, const void* logits, const float* lse, const lon
 
 SC_API int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
                       long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank,
-                      const float* alpha, const float* nll, const float* gscale, void* grad, hipStream_t stream) {
-  SC_CHECK_ARG(logits && lse && in_len && tgt && tgt_len && alpha && nll && gscale && grad, "sc_ctc_bwd: null pointer");
+                      const float* alpha, const float* nll, const float* gscale, float* beta, void* grad, hipStream_t stream) {
+  SC_CHECK_ARG(logits && lse && in_len && tgt && tgt_len && alpha && nll && gscale && beta && grad, "sc_ctc_bwd: null pointer");
   SC_CHECK_ARG(B >= 1 && Tmax >= 1 && V >= 1 && Smax >= 1 && Smax <= kMaxS, "sc_ctc_bwd: bad sizes");
-  CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, const_cast<float*>(alpha), const_cast<float*>(nll), gscale, grad};
+  SC_CHECK_ARG(V <= (1 << 16), "sc_ctc_bwd: vocabulary %d > 65536 (label bitmap in LDS)", V);
+  CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, const_cast<float*>(alpha), const_cast<float*>(nll), gscale, grad, beta};
   if (dtype == 0) {
-    hipLaunchKernelGGL(ctc_dense_grad_kernel<float>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(ctc_beta_grad_kernel<float>, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ctc_beta_kernel<float>, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ctc_grad_kernel<float>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(ctc_dense_grad_kernel<unsigned short>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(ctc_beta_grad_kernel<unsigned short>, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ctc_beta_kernel<unsigned short>, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(ctc_grad_kernel<unsigned short>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   }
   SC_LAUNCH_CHECK("ctc backward kernels");
   return SC_OK;

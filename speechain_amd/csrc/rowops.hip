@@ -119,21 +119,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
 }
 
 // out[j][k] = sum_p part[(p * nout + j) * D + k]   (deterministic second stage of column reductions).
-// grid (ceil(D/16), nout); 256 threads = 16 columns x 16 partial-lanes, combined through LDS.
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* part, int P, int nout, int D, float* out0, float* out1) {
-  __shared__ float red[16][17];
+// grid (ceil(D/16), nout); 1024 threads = 16 columns x 64 partial-lanes, combined through LDS in a fixed order.  The
+// stage is a few MB read by few workgroups, i.e. latency-bound: every lane keeps up to 16 loads in flight.
+__global__ __launch_bounds__(1024) void reduce_parts_kernel(const float* part, int P, int nout, int D, float* out0, float* out1) {
+  __shared__ float red[64][17];
   const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
   const int k = blockIdx.x * 16 + c;
   const int j = blockIdx.y;
   float s = 0.f;
-  if (k < D)
-    for (int p = pl; p < P; p += 16) s += part[((long long)p * nout + j) * D + k];
+  if (k < D) {
+    for (int p0 = pl; p0 < P; p0 += 64 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int pp = p0 + 64 * u;
+        v[u] = pp < P ? part[((long long)pp * nout + j) * D + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
   red[pl][c] = s;
   __syncthreads();
   if (pl == 0 && k < D) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += red[i][c];
+    for (int i = 0; i < 64; ++i) t += red[i][c];
     (j == 0 ? out0 : out1)[k] = t;
   }
 }
@@ -382,7 +393,7 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
                 (float*)workspace, R, D, rpb);
   SC_LAUNCH_CHECK("layernorm_bwd_kernel");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(256), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(1024), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
   SC_LAUNCH_CHECK("reduce_parts_kernel");
   return SC_OK;
 }
@@ -404,7 +415,7 @@ SC_API int sc_colsum(int dtype, const void* x, long long R, int N, long long ld,
   strips = (R + rpb - 1) / rpb;
   SC_DISPATCH_T(dtype, colsum_kernel, dim3(sc_cdiv(N, 64), (unsigned)strips), dim3(256), 0, stream, x, R, N, ld, rpb, (float*)workspace);
   SC_LAUNCH_CHECK("colsum_kernel");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(N, 16), 1), dim3(256), 0, stream, (const float*)workspace, (int)strips, 1, N, out, out);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(N, 16), 1), dim3(1024), 0, stream, (const float*)workspace, (int)strips, 1, N, out, out);
   SC_LAUNCH_CHECK("reduce_parts_kernel");
   return SC_OK;
 }

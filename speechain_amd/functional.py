@@ -914,8 +914,9 @@ class _CTC(torch.autograd.Function):
         if zero_infinity:
             gscale = torch.where(torch.isinf(nll), torch.zeros_like(gscale), gscale)
         grad = torch.empty_like(logits)
+        beta = torch.empty_like(alpha)  # (B, T, Smax) workspace of the backward recursion
         lib.call("sc_ctc_bwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax, blank,
-                 _p(alpha), _p(nll), _p(gscale), _p(grad), stream())
+                 _p(alpha), _p(nll), _p(gscale), _p(beta), _p(grad), stream())
         return grad, None, None, None, None, None
 
 

@@ -184,6 +184,32 @@ def test_losses(golden, mode):
     close(torch.autograd.grad(loss, lg)[0], g["ctc_grad"], gt, "ctc grad")
 
 
+def test_ctc_edge_cases_vs_oracle():
+    """Infeasible alignment (more labels + forced blanks than frames: zero_infinity path), an utterance shorter than the
+    padded batch (zero gradient beyond its length), a label repeated three times, a single-label target."""
+    from speechain_amd.criterion.ctc import CTCLoss
+
+    gen = torch.Generator().manual_seed(5)
+    B, T, V = 4, 9, 23
+    logits = torch.randn(B, T, V, generator=gen)
+    E = V - 1  # <sos/eos>, at both ends of every sentence as the criterion's interface requires (criterion/ctc.py:48-52)
+    text = torch.tensor([[E, 3, 4, 5, 6, E, 0, 0, 0, 0],      # feasible
+                         [E, 7, 7, 7, 7, 7, 7, E, 0, 0],      # 6 equal labels need 11 frames > 9: infinite loss -> zeroed
+                         [E, 9, 2, 9, 8, 9, E, 0, 0, 0],      # the same label three times, not adjacent
+                         [E, 11, E, 0, 0, 0, 0, 0, 0, 0]])    # one label
+    text_len = torch.tensor([6, 8, 7, 3])
+    enc_len = torch.tensor([9, 9, 7, 3])
+    lg_ref = logits.clone().requires_grad_()
+    ref = R.ctc_loss(lg_ref, enc_len, text, text_len)
+    gref = torch.autograd.grad(ref, lg_ref)[0]
+    lg = logits.cuda().requires_grad_()
+    loss = CTCLoss()(lg, enc_len.cuda(), text.cuda(), text_len.cuda())
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    g = torch.autograd.grad(loss, lg)[0].cpu()
+    assert float((g - gref).abs().max()) < 1e-6 + 1e-4 * float(gref.abs().max())
+    assert float(g[1].abs().max()) == 0.0 and float(g[2, 7:].abs().max()) == 0.0 and float(g[3, 3:].abs().max()) == 0.0
+
+
 def test_ctc_full_size_vs_oracle():
     """BASELINE shapes: (32, 249, 5000) logits, 62 labels incl. repeats; value and gradient vs torch's CPU CTC."""
     from speechain_amd.criterion.ctc import CTCLoss
