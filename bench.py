@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
+    ap.add_argument("--prenet-dims", default="64,64",
+                    help="conv channels of the Conv2d prenet in front of the encoder (outside the named hot path, plain torch/MIOpen). "
+                         "64,64 = the reference module's default; 512,512 = what the LibriSpeech transformer recipes set (conv_dims = d_model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -95,16 +98,26 @@ def synth_text(seed: int, device, vocab: int = 5000):
     return text.to(device), torch.full((BATCH,), TEXT_LEN, dtype=torch.int64, device=device)
 
 
-class ASRTrainStepWorkload:
-    """BASELINE.json configs[2] driven from waveforms: frontend -> SpecAugment -> conv2d prenet [64,64] (torch, outside the named
-    path) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip -> Adam (Noam), bf16 compute."""
+PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + LeakyReLU + Linear, as the recipes configure it) is OUTSIDE the named hot path "
+               "and runs on stock torch/MIOpen in fp32. conv_dims [64,64] is the reference module's default; the LibriSpeech "
+               "transformer recipes set conv_dims = d_model = [512,512] (recipes/asr/librispeech/train-clean-100/exp_cfg/"
+               "100-bpe5k_transformer-large_lr2e-3.yaml:197-206), whose convolutions cost more FLOPs than the 12-layer encoder "
+               "(SURVEY.md section 2 row 9, section 8f #2): run --prenet-dims 512,512 for the full-recipe step")
 
-    name = ("ASR transformer-base train step (12enc/6dec d512 h8 ffn2048 V5000, bf16) from 32x10s@16kHz waveforms: frontend + "
-            "specaug + conv2d-prenet[64,64] + encoder + decoder + 0.7CE/0.3CTC + backward + clip + Adam (BASELINE configs[2])")
+
+class ASRTrainStepWorkload:
+    """BASELINE.json configs[2] driven from waveforms: frontend -> SpecAugment -> conv2d prenet (torch/MIOpen, outside the named
+    path; channels from --prenet-dims) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip ->
+    Adam (Noam), bf16 compute."""
+
     dtype = "bf16"
     dominant = "gemm_bf16_kernel (all layouts)"
 
-    def __init__(self, device, seed, world):
+    def __init__(self, device, seed, world, prenet_dims=(64, 64)):
+        self.prenet_dims = tuple(prenet_dims)
+        self.name = ("ASR transformer-base train step (12enc/6dec d512 h8 ffn2048 V5000, bf16) from 32x10s@16kHz waveforms: frontend + "
+                     f"specaug + conv2d-prenet{list(self.prenet_dims)} + encoder + decoder + 0.7CE/0.3CTC + backward + clip + Adam "
+                     "(BASELINE configs[2])")
         from speechain_amd import functional as Fn
         from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
         from speechain_amd.harness import ASRTransformer, Conv2dSubsample
@@ -116,7 +129,7 @@ class ASRTrainStepWorkload:
         torch.manual_seed(0)  # identical initial weights on every rank
         self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
-        self.prenet = Conv2dSubsample(80, (64, 64), 512).to(device).train()
+        self.prenet = Conv2dSubsample(80, self.prenet_dims, 512).to(device).train()
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
         for m in (self.prenet, self.model):
             for p in m.parameters():
@@ -227,7 +240,7 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def cpu_baseline_train(seconds: float):
+def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
     """The oracle's ASR step (frontend -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
     on a bounded sample: ~`seconds` of steps over 4 of the 32 utterances (same per-utterance shapes), scaled to utterances/s."""
     from oracle import cpu_ref as R
@@ -237,7 +250,7 @@ def cpu_baseline_train(seconds: float):
     torch.set_num_threads(cores)
     nb = 4
     torch.manual_seed(0)
-    prenet = Conv2dSubsample(80, (64, 64), 512)
+    prenet = Conv2dSubsample(80, tuple(prenet_dims), 512)
     model = ASRTransformer(**ASR_MODEL)
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("posenc")) for k, v in model.state_dict().items()}
     P["embed.weight"] = P.pop("embed.embed.weight")
@@ -313,7 +326,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     torch.manual_seed(1234 + rank)
-    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world)
+    prenet_dims = tuple(int(c) for c in args.prenet_dims.split(","))
+    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world, prenet_dims)
     for _ in range(args.warmup):
         wl.step(False)
 
@@ -363,11 +377,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": SAMPLES,
                        "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
-                                    f"dp{world}: per-GPU batch 32, bucketed RCCL gradient all-reduce overlapped with backward")},
+                                    f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
+                                    "buckets, issued between the backward hipGraph and the optimizer hipGraph (not overlapped with "
+                                    "backward in this graph-captured step)")},
             "roofline": roof,
         }
+        if args.workload == "asr_train_step":
+            line["config"]["prenet"] = PRENET_NOTE
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds, prenet_dims)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
