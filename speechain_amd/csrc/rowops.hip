@@ -118,6 +118,160 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
   }
 }
 
+// ---- bf16 LayerNorm with 16-byte accesses: lane l owns the 8 consecutive elements 8 (l + 64 c) .. + 7 of chunk c < NV ----
+// (the element-per-lane kernels above issue one 2-byte load per lane per instruction: instruction-bound, 1.5 TB/s).
+// Needs D % 8 == 0, 16-byte aligned rows and D <= 512 NV.
+__device__ __forceinline__ void ln_unpack8(const uint4& u, float (&f)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(w[e] << 16);
+    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 ln_pack8(const float (&f)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = (unsigned)sc_f32_to_bf16(f[2 * e]) | ((unsigned)sc_f32_to_bf16(f[2 * e + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void ln_load8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const unsigned short* x, const float* gamma, const float* beta,
+                                                                unsigned short* y, float* mean, float* rstd, long long R, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const long long base = row * D;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int k = 8 * (lane + 64 * c);
+    if (k < D) {
+      ln_unpack8(*reinterpret_cast<const uint4*>(x + base + k), v[c]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[c][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mu = sc_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+    if (8 * (lane + 64 * c) < D)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[c][e] - mu;
+        q += d * d;
+      }
+  const float rs = rsqrtf(sc_wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int k = 8 * (lane + 64 * c);
+    if (k < D) {
+      float g[8], b[8], o[8];
+      ln_load8f(gamma + k, g);
+      ln_load8f(beta + k, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+      *reinterpret_cast<uint4*>(y + base + k) = ln_pack8(o);
+    }
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
+// dx for a strip of rows; per-workgroup partial dgamma / dbeta go to part[(2*blockIdx.x + {0,1}) * D + k]
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned short* dy, const unsigned short* x, const float* mean,
+                                                                const float* rstd, const float* gamma, unsigned short* dx, float* part,
+                                                                long long R, int D, int rows_per_block) {
+  extern __shared__ float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float gm[NV][8], dg[NV][8], db[NV][8];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int k = 8 * (lane + 64 * c);
+    if (k < D) ln_load8f(gamma + k, gm[c]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[c][e] = db[c][e] = 0.f;
+      if (k >= D) gm[c][e] = 0.f;
+    }
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(R, r0 + rows_per_block);
+  for (long long row = r0 + wid; row < r1; row += 4) {
+    const long long base = row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float g[NV][8], xh[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int k = 8 * (lane + 64 * c);
+      if (k < D) {
+        float d[8];
+        ln_unpack8(*reinterpret_cast<const uint4*>(dy + base + k), d);
+        ln_unpack8(*reinterpret_cast<const uint4*>(x + base + k), xh[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[c][e] = (xh[c][e] - mu) * rs;
+          g[c][e] = d[e] * gm[c][e];
+          dg[c][e] += d[e] * xh[c][e];
+          db[c][e] += d[e];
+          s1 += g[c][e];
+          s2 += g[c][e] * xh[c][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[c][e] = xh[c][e] = 0.f;
+      }
+    }
+    s1 = sc_wave_sum(s1) / (float)D;
+    s2 = sc_wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int k = 8 * (lane + 64 * c);
+      if (k < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2);
+        *reinterpret_cast<uint4*>(dx + base + k) = ln_pack8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int k = 8 * (lane + 64 * c);
+    if (k < D)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wid * 2 + 0) * D + k + e] = dg[c][e];
+        red[(wid * 2 + 1) * D + k + e] = db[c][e];
+      }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < D; k += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[(w * 2 + 0) * D + k];
+      b += red[(w * 2 + 1) * D + k];
+    }
+    part[((long long)blockIdx.x * 2 + 0) * D + k] = a;
+    part[((long long)blockIdx.x * 2 + 1) * D + k] = b;
+  }
+}
+
 // out[j][k] = sum_p part[(p * nout + j) * D + k]   (deterministic second stage of column reductions).
 // grid (ceil(D/16), nout); 1024 threads = 16 columns x 64 partial-lanes, combined through LDS in a fixed order.  The
 // stage is a few MB read by few workgroups, i.e. latency-bound: every lane keeps up to 16 loads in flight.
@@ -367,7 +521,15 @@ SC_API int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const 
                             long long R, int D, float eps, hipStream_t stream) {
   SC_CHECK_ARG(x && gamma && beta && y, "sc_layernorm_fwd: null pointer");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_fwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
-  SC_DISPATCH_TN(dtype, D, layernorm_fwd_kernel, 8, 16, 32, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, D, eps);
+  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0);
+  if (vec) {
+    const dim3 grid((unsigned)((R + 3) / 4));
+    if (D <= 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, dim3(256), 0, stream, (const unsigned short*)x, gamma, beta, (unsigned short*)y, mean, rstd, R, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, grid, dim3(256), 0, stream, (const unsigned short*)x, gamma, beta, (unsigned short*)y, mean, rstd, R, D, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_vec_kernel<4>, grid, dim3(256), 0, stream, (const unsigned short*)x, gamma, beta, (unsigned short*)y, mean, rstd, R, D, eps);
+  } else {
+    SC_DISPATCH_TN(dtype, D, layernorm_fwd_kernel, 8, 16, 32, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, D, eps);
+  }
   SC_LAUNCH_CHECK("layernorm_fwd_kernel");
   return SC_OK;
 }
@@ -390,8 +552,17 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   blocks = (R + rpb - 1) / rpb;
   const size_t smem = (size_t)8 * D * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_layernorm_bwd: D too large for the LDS reduction");
-  SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
-                (float*)workspace, R, D, rpb);
+  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) % 16 == 0);
+  if (vec) {
+    const dim3 grid((unsigned)blocks);
+    const unsigned short *dy16 = (const unsigned short*)dy, *x16 = (const unsigned short*)x;
+    if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
+    else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
+  } else {
+    SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
+                  (float*)workspace, R, D, rpb);
+  }
   SC_LAUNCH_CHECK("layernorm_bwd_kernel");
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(1024), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
   SC_LAUNCH_CHECK("reduce_parts_kernel");

@@ -3,6 +3,8 @@ reference modules: forward outputs, returned attention maps, and input/parameter
 
 float32 mode is the parity mode (exact-f32 matrix cores): tolerances 2e-4 abs on activations, 1e-3 rel on gradients.
 bfloat16 mode (training) is checked against the same fixtures with bf16-rounding tolerances."""
+import math
+
 import pytest
 import torch
 
@@ -164,6 +166,31 @@ def test_stacks(golden, mode):
     close(sa[1], g["dec.self_att1"], pt, "dec self att")
     close(ea[1], g["dec.encdec_att1"], pt, "dec encdec att")
     close(hd[0], g["dec.hid0"], t, "dec hid0")
+
+
+@pytest.mark.parametrize("R,D", [(7968, 512), (2016, 512), (37, 64), (301, 520), (129, 1536), (65, 2048), (50, 100)])
+def test_layernorm_bf16_vs_torch_fp32(R, D):
+    """nn.LayerNorm(eps=1e-6) forward and backward in bf16 through the 16-byte-access kernels (D % 8 == 0) and the
+    element-per-lane ones (D = 100) against torch fp32 on the same bf16-rounded inputs.  Outputs are bf16: one rounding
+    (2^-8 relative) on top of fp32 arithmetic; parameter gradients are f32 sums over R rows of bf16-rounded dy."""
+    from speechain_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(R + D)
+    x = (torch.randn(R, D, generator=gen) * 2 + 0.5).bfloat16()
+    w = torch.randn(R, D, generator=gen).bfloat16()
+    gamma = (1 + 0.1 * torch.randn(D, generator=gen))
+    beta = 0.1 * torch.randn(D, generator=gen)
+    xr, gr, br = x.float().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    gxr, ggr, gbr = torch.autograd.grad((yr * w.float()).sum(), [xr, gr, br])
+    xc, gc, bc = x.cuda().requires_grad_(), gamma.cuda().requires_grad_(), beta.cuda().requires_grad_()
+    y = Fn.layer_norm(xc, gc, bc, 1e-6)
+    assert y.dtype == torch.bfloat16
+    gx, gg, gb = torch.autograd.grad((y.float() * w.cuda().float()).sum(), [xc, gc, bc])
+    assert torch.allclose(y.float().cpu(), yr, atol=2e-2, rtol=1e-2), float((y.float().cpu() - yr).abs().max())
+    assert torch.allclose(gx.float().cpu(), gxr, atol=3e-2, rtol=2e-2), float((gx.float().cpu() - gxr).abs().max())
+    scale = math.sqrt(R)
+    assert float((gg.cpu() - ggr).abs().max()) < 2e-2 * scale and float((gb.cpu() - gbr).abs().max()) < 2e-2 * scale
 
 
 def test_losses(golden, mode):
