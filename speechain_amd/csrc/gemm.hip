@@ -836,6 +836,193 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   epilogue_wave_fused<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 TN split-K kernel on the same LDS-DMA pipeline: the wgrad product dW = dz^T x, both operands read TRANSPOSED
+// (contraction index = token = slow dimension, rows contiguous along the features).
+//
+// An operand tile is 32 k-rows x 128 columns (256-byte rows); one LDS-DMA wave-instruction moves 4 k-rows (1 KB).
+// MFMA fragments come from the transposing read ds_read_b64_tr_b16, whose 16-lane groups touch 4 consecutive k-rows at
+// the same column offsets -- with linear 256-byte rows those four addresses share their banks (4-way conflict), and DMA
+// rows cannot be padded.  So the 16-byte chunk index is XOR-swizzled with 4 * (k-row & 3) on the SOURCE side of the DMA
+// (lane l of a granule fills LDS slot (row l >> 4, chunk l & 15) from source chunk (l & 15) ^ (4 (l >> 4))) and by the
+// same involution in the read address: the 16 lanes of a group then cover 16 distinct 8-byte bank pairs.
+// Split-K only (raw f32 partial tiles to slab z, summed by splitk_reduce_kernel); needs K % 32 == 0, M % 8 == N % 8 == 0
+// and 16-byte aligned rows -- anything else takes the register-staged kernel.
+// STATUS: correct (tests/test_gemm_gpu.py drives it through the C ABI) but NOT the default: on the train step it measured
+// 16.03 ms vs 15.83 ms for the register-staged TN kernel (GEMM aggregate 233 vs 251 TFLOP/s, same box, same commit).  With a
+// 32-token K tile a wave issues only 8 MFMAs per barrier, so the per-tile overhead (barrier, counted wait, tr reads, 64-bit
+// source offsets) dominates in both kernels; the staging path was not the limiter here.  Enabled with SC_GEMM_TN_DMA=1.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t read_frag16_tr_swz(const unsigned short* tile, int rbase, int ks, int lane) {
+  const int g = lane >> 4, ip = lane & 15, q = ip >> 2, pp = ip & 3;
+  const int kr = ks * 16 + 8 * (g >> 1) + q;         // k-row of the `lo` read (kr & 3 == q); `hi` is k-row kr + 4: next granule
+  const int col = rbase + 16 * (g & 1) + 4 * pp;
+  const unsigned short* a = tile + (kr >> 2) * 512 + q * 128 + (((col >> 3) ^ (q << 2)) << 3) + (col & 7);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a + 512));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArgs p) {
+  constexpr int STAGES = 4, OPER_ELEMS = BM * BK16, STAGE_ELEMS = 2 * OPER_ELEMS;  // 8 KB per operand tile, 16 KB per stage
+  extern __shared__ __attribute__((aligned(1024))) unsigned short dsmem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int h = lane >> 5, li = lane & 31;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+    if (nwg >= 16) {
+      const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+      const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = id / gx;
+      bx = id - by * gx;
+    }
+  }
+  const int n0 = bx * BN, m0 = by * BM;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.ksplit_len;
+  const int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nk = (kend - kbeg) / BK16;  // whole tiles only (K % 32 == 0 is a launch condition)
+
+  // Each wave stages granules wid and wid + 4 of both operands: granule gch = k-rows 4 gch .. 4 gch + 3.  Lane l fills LDS
+  // slot (row l >> 4, chunk l & 15) from source chunk (l & 15) ^ (4 (l >> 4)); column chunks beyond the matrix are clamped to
+  // the last valid chunk (their products are never stored).
+  const unsigned short* A = (const unsigned short*)p.A;
+  const unsigned short* B = (const unsigned short*)p.B;
+  const int q = lane >> 4, schunk = (lane & 15) ^ (q << 2);
+  const int acol = min(m0 + schunk * 8, p.M - 8), bcol = min(n0 + schunk * 8, p.N - 8);
+  const unsigned short* asrc[2];
+  const unsigned short* bsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int krow = (wid + 4 * i) * 4 + q;
+    asrc[i] = A + (long long)(kbeg + krow) * p.lda + acol;
+    bsrc[i] = B + (long long)(kbeg + krow) * p.ldb + bcol;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define SC_TN_ISSUE(T)                                                                                                  \
+  do {                                                                                                                  \
+    unsigned short* st_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                  \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + (long long)(T) * BK16 * p.lda),                           \
+                                       (sc_lptr_t)(st_ + (wid + 4 * i_) * 512), 16, 0, 0);                              \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + (long long)(T) * BK16 * p.ldb),                           \
+                                       (sc_lptr_t)(st_ + OPER_ELEMS + (wid + 4 * i_) * 512), 16, 0, 0);                 \
+    }                                                                                                                   \
+  } while (0)
+
+  if (nk > 0) SC_TN_ISSUE(0);
+  if (nk > 1) SC_TN_ISSUE(1);
+  if (nk > 2) SC_TN_ISSUE(2);
+
+  // bias gradient: column sums of A over the contraction, taken from the landed A tiles by the workgroups of the first
+  // N tile.  Thread t reads column chunk t & 15 of k-rows (t >> 4) and (t >> 4) + 16 -- the same ownership as in the
+  // register-staged kernel, so the final cross-thread reduction is identical.
+  const bool csum = p.colsum_part != nullptr && n0 == 0;
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  int csoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kr = (tid >> 4) + 16 * i;
+    csoff[i] = (kr >> 2) * 512 + (kr & 3) * 128 + (((tid & 15) ^ ((kr & 3) << 2)) << 3);
+  }
+
+  constexpr int LPT = 4;  // DMA instructions per wave per tile
+  for (int t = 0; t < nk; ++t) {
+    const int ahead = min(2, nk - 1 - t);
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nk) SC_TN_ISSUE(t + 3);
+    const unsigned short* as = dsmem + (t % STAGES) * STAGE_ELEMS;
+    const unsigned short* bs = as + OPER_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = read_frag16_tr_swz(as, wr * 64 + i * 32, ks, lane);
+        b[i] = read_frag16_tr_swz(bs, wc * 64 + i * 32, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (csum) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 u = *(const uint4*)(as + csoff[i]);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cs[2 * e] += __uint_as_float(w[e] << 16);
+          cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+    }
+  }
+#undef SC_TN_ISSUE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become staging
+
+  if (csum) {
+    float* red = (float*)dsmem;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + (tid & 15) * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < 128 && m0 + tid < p.M) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) v += red[g * 128 + tid];
+      p.colsum_part[(long long)z * p.M + m0 + tid] = v;
+    }
+    __syncthreads();
+  }
+
+  // raw partial tile -> slab z (f32); the reduce kernel finishes the job
+  float* stage = (float*)dsmem + wid * 32 * STG_LD;
+  float* slab = (float*)p.C + (long long)z * p.M * p.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * h) * STG_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int it = 0; it < 8; ++it) {
+      const int qq = lane + 64 * it;
+      const int row = qq >> 4, c4 = (qq & 15) * 4;
+      const int m = m0 + wr * 64 + i * 32 + row, n = n0 + wc * 64 + c4;
+      if (m < p.M && n < p.N) {
+        const f32x4 v = *(const f32x4*)(stage + row * STG_LD + c4);
+        float* dst = slab + (long long)m * p.ldc + n;
+        if (n + 4 <= p.N && p.c_vec32) *(f32x4*)dst = v * p.alpha;
+        else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e] * p.alpha;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
+}
+
 template <int WM, int WN, int MI>
 int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
   constexpr int TM = WM * MI * 32, TN = WN * 64;
@@ -1090,6 +1277,16 @@ SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C
   float* part2 = (float*)workspace + (long long)splitk * M * N;
   a.colsum_part = colsum ? part2 : nullptr;
   int rc;
+  const bool tn_dma = ta && tb && a.a_vec && a.b_vec && K % BK16 == 0 && M % 8 == 0 && N % 8 == 0 && M >= 8 && N >= 8 &&
+                      getenv("SC_GEMM_TN_DMA") != nullptr;  // opt-in: measured 1.3 % slower per train step than the register-staged kernel
+  if (tn_dma) {
+    constexpr size_t smem = (size_t)4 * 2 * BM * BK16 * sizeof(unsigned short);  // four 16 KB stages
+    static_assert(smem >= (size_t)16 * 128 * sizeof(float) && smem >= (size_t)4 * 32 * STG_LD * sizeof(float), "stages must cover the staging tiles");
+    dim3 grid(sc_cdiv(N, BN), sc_cdiv(M, BM), slices);
+    hipLaunchKernelGGL(gemm_bf16_tn_dma_splitk_kernel, grid, dim3(256), smem, stream, a);
+    hipError_t e = hipGetLastError();
+    rc = e == hipSuccess ? SC_OK : sc_set_error(SC_ERR_LAUNCH, "gemm_bf16_tn_dma_splitk_kernel: %s", hipGetErrorString(e));
+  } else
   if (!ta && !tb) rc = launch(gemm_bf16_kernel<false, false>, a, slices, stream, "gemm_bf16<NT> split-K");
   else if (!ta && tb) rc = launch(gemm_bf16_kernel<false, true>, a, slices, stream, "gemm_bf16<NN> split-K");
   else if (ta && !tb) rc = launch(gemm_bf16_kernel<true, false>, a, slices, stream, "gemm_bf16<TT> split-K");

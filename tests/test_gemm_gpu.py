@@ -141,3 +141,25 @@ def test_wgrad_bias_gradient_from_the_same_launch(M, N, K):
         assert torch.equal(dW, Fn.wgrad(Fn.dcode(dz), dz, x))
         # deterministic: same launch twice, same bits
         assert torch.equal(db, Fn.wgrad(Fn.dcode(dz), dz, x, bias=True)[1])
+
+
+@pytest.mark.parametrize("T,N,K,splitk", [(1024, 128, 128, 32), (1024, 256, 136, 16), (2048, 5000, 520, 4), (7968, 1536, 512, 8),
+                                          (640, 8, 8, 2), (992, 264, 72, 31)])
+def test_tn_split_k_dma_kernel_through_the_c_abi(monkeypatch, T, N, K, splitk):
+    """dW (N, K) = dz^T x and db = column sums of dz straight through sc_gemm_splitk on the LDS-DMA TN kernel (tokens % 32 == 0,
+    N % 8 == K % 8 == 0): one or two K tiles per slice, partial 128-column tiles, tiny outputs -- against fp64 of the same
+    bf16 values, and bit-identical to the register-staged kernel's slabs order-independent part (same reduce kernel)."""
+    from speechain_amd._lib import lib, stream
+
+    monkeypatch.setenv("SC_GEMM_TN_DMA", "1")  # the kernel is opt-in (it is slower than the register-staged one: DESIGN.md section 6)
+    dz, x = _mk((T, N), torch.bfloat16, 40), _mk((T, K), torch.bfloat16, 41)
+    dW = torch.empty(N, K, device="cuda")
+    db = torch.empty(N, device="cuda")
+    ws = torch.empty(lib.value("sc_gemm_splitk_workspace", N, K, splitk), dtype=torch.uint8, device="cuda")
+    lib.call("sc_gemm_splitk", 1, 1, Fn._p(dz), Fn._p(x), Fn._p(dW), N, K, T, N, K, 1.0, splitk, 0, Fn._p(db), Fn._p(ws), ws.numel(),
+             stream())
+    ref = dz.double().t() @ x.double()
+    assert torch.allclose(dW.double(), ref, atol=0.05 * math.sqrt(T / 64), rtol=2e-2), float((dW.double() - ref).abs().max())
+    rb = dz.double().sum(0)
+    bound = dz.double().abs().sum(0) * T * 2.0 ** -23 + 1e-6
+    assert bool(((db.double() - rb).abs() <= bound).all())
