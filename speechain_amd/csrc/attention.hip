@@ -9,6 +9,7 @@
 // per row (mask byte / causal / length, dropout from the device seed cell); P is written back in place as bf16; O = P V with
 // V fragments read through the transposing LDS read, the two key halves combined through LDS.
 #include "sc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -198,6 +199,193 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel(AttnArgs p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming ("flash") forward for key masks that do not depend on the query (none, (B, 1, Tk), causal flag): any Tk.
+//
+// One 256-thread workgroup per (batch, head, 128-query tile); wave w owns queries 32 w .. 32 w + 31 and keeps its Q rows
+// in registers.  K and V stream through LDS in 64-key tiles (LDS-DMA, three 16 KB stages, one barrier per tile; rows are
+// 128 bytes and cannot be padded, so the 16-byte chunk index is XOR-ed with (key & 7) on the source side and in the
+// read addresses: conflict-free for the row-major K fragments and the transposing V reads alike).
+//
+// The score tile is computed TRANSPOSED, S^T = K Q^T (keys x queries): in the 32x32 accumulator layout a lane then holds
+// ONE query (column lane & 31) and 16 keys per 32-key block in its registers, so the online softmax (running max / sum,
+// rescale) is register arithmetic plus one v_permlane32_swap per tile -- no score image in LDS, no shuffles per row.
+// The same registers, packed to bf16, are the B operand of O^T += V^T P~^T (head dims x queries): lane half h supplies
+// keys 4h + {0..3, 8..11} (+16, +32, +48) of the tile, and the V fragments are read with the matching key order.
+// Dropout indices, the LSE definition (natural log) and the zero output of an all-masked row are those of attn_fwd_kernel,
+// so attn_bwd_kernel consumes either forward.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* at_gptr_t;
+typedef __attribute__((address_space(3))) void* at_lptr_t;
+
+__global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
+  constexpr int KT = 64, STAGES = 3, TILE = KT * DH, STAGE_ELEMS = 2 * TILE;  // K tile + V tile per stage (16 KB)
+  extern __shared__ __attribute__((aligned(1024))) unsigned short dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int z = blockIdx.y, b = z / p.H, hd = z - b * p.H;
+  const int qg = blockIdx.x * 128 + wid * 32 + li;  // this lane's query
+  const int qc = min(qg, p.Tq - 1);
+  const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
+  const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
+  const int nt = (p.Tk + KT - 1) / KT;
+
+  // DMA sources: a granule is 8 key rows x 128 B; wave w stages granules 2w, 2w+1 of K and of V.  Lane l fills LDS slot
+  // (row l >> 3, chunk l & 7) from source chunk (l & 7) ^ (row & 7); rows beyond Tk are clamped (masked out below).
+  const int grow = lane >> 3, gch = (lane & 7) ^ (grow & 7);
+#define AT_ISSUE(T)                                                                                                      \
+  do {                                                                                                                   \
+    unsigned short* st_ = dsm + ((T) % STAGES) * STAGE_ELEMS;                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                   \
+      const int g_ = 2 * wid + i_;                                                                                       \
+      const long long src_ = (long long)min((T) * KT + g_ * 8 + grow, p.Tk - 1) * p.ldk + gch * 8;                       \
+      __builtin_amdgcn_global_load_lds((at_gptr_t)(Kg + src_), (at_lptr_t)(st_ + g_ * 512), 16, 0, 0);                   \
+      __builtin_amdgcn_global_load_lds((at_gptr_t)(Vg + src_), (at_lptr_t)(st_ + TILE + g_ * 512), 16, 0, 0);            \
+    }                                                                                                                    \
+  } while (0)
+  // Q^T operand of this lane's query: head dims 16 ks + 8 h .. + 7
+  bf16x8_t qf[4];
+  {
+    const unsigned short* qrow = p.Q + b * p.q_b + hd * DH + (long long)qc * p.ldq;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + ks * 16 + h * 8);
+  }
+  const unsigned char* mrow = p.mask ? p.mask + b * p.mask_b : nullptr;
+  // key validity, lane i answers for key 64 t + i; the byte of tile t + 1 is fetched before the DMA of tile t + 2 is issued,
+  // so that waiting for it never drains the prefetched tiles (vmcnt counts in order)
+  auto key_ok = [&](int t_) {
+    const int kk = t_ * KT + lane;
+    return kk < p.Tk && (mrow == nullptr || mrow[min(kk, p.Tk - 1)] != 0);
+  };
+  const float c1 = p.scale * 1.4426950408889634f;  // scores are kept in log2 units: p = exp2(c1 s - m)
+  const bool drop = p.drop_p > 0.f;
+  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const unsigned thr = sc_drop_threshold(p.drop_p);
+  const unsigned long long idxq = p.offset + ((unsigned long long)z * p.Tq + qc) * p.ldp;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane half's share of the row sum
+
+  bool kok = key_ok(0);
+  if (nt > 0) AT_ISSUE(0);
+  if (nt > 1) AT_ISSUE(1);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool kok_next = (t + 1 < nt) ? key_ok(t + 1) : false;
+    if (t + 2 < nt) AT_ISSUE(t + 2);
+    const unsigned short* ks_ = dsm + (t % STAGES) * STAGE_ELEMS;
+    const unsigned short* vs_ = ks_ + TILE;
+    // key validity of the tile as a 64-bit lane mask
+    unsigned long long bits = __ballot(kok);
+    kok = kok_next;
+    bits >>= 4 * h;  // register r of block j then is bit 32 j + (r & 3) + 8 (r >> 2)
+
+    // ---- S^T = K Q^T: two 32-key blocks x 32 queries ----
+    f32x16 s2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s2[j][r] = 0.f;
+      const int krow = 32 * j + li;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t a = *(const bf16x8_t*)(ks_ + krow * DH + (((2 * ks + h) ^ (krow & 7)) << 3));
+        s2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s2[j], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query ----
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kb = 32 * j + (r & 3) + 8 * (r >> 2);  // + 4 h: key inside the tile
+        bool ok = (bits >> kb) & 1ull;
+        if (p.causal) ok = ok && (t * KT + kb + 4 * h <= qg);
+        const float x = ok ? s2[j][r] * c1 : -INFINITY;
+        s2[j][r] = x;
+        mloc = fmaxf(mloc, x);
+      }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // both halves: max over all 64 keys
+    }
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
+    const float msub = (m_new == -INFINITY) ? 0.f : m_new;
+    float lsum = 0.f;
+    bf16x8_t pf[4];  // P~^T operand: k-step ks = block ks >> 1, registers 8 (ks & 1) .. + 7
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        float p0 = exp2f(s2[j][r] - msub), p1 = exp2f(s2[j][r + 1] - msub);  // exp2(-inf) = 0 for masked keys
+        lsum += p0 + p1;
+        if (drop) {
+          const int kb = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;  // even key: (kb, kb + 1) share one hash word
+          const unsigned hsh = sc_rand_pair(seed, (idxq + (unsigned long long)(t * KT + kb)) >> 1);
+          p0 = ((hsh & 0xFFFFu) < thr) ? 0.f : p0 * p.drop_keep;
+          p1 = ((hsh >> 16) < thr) ? 0.f : p1 * p.drop_keep;
+        }
+        const int ks = 2 * j + (r >> 3), e = r & 7;
+        pf[ks][e] = (__bf16)p0;
+        pf[ks][e + 1] = (__bf16)p1;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+    // ---- O^T += V^T P~^T: two 32-head-dim blocks; k-step ks covers keys 32 (ks >> 1) + 16 (ks & 1) + 4 h + {0..3, 8..11} ----
+    {
+      const int g = lane >> 4, ip = lane & 15, q = ip >> 2, pp = ip & 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kbase = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * (g >> 1) + q;  // this lane's key row of the `lo` read; `hi` is + 8
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = 32 * j + 16 * (g & 1) + 4 * pp;
+          const unsigned short* a0 = vs_ + kbase * DH + (((col >> 3) ^ (kbase & 7)) << 3) + (col & 7);
+          const unsigned short* a1 = vs_ + (kbase + 8) * DH + (((col >> 3) ^ ((kbase + 8) & 7)) << 3) + (col & 7);
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a0);
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a1);
+          const s16x8_t v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v8), pf[ks], o[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef AT_ISSUE
+
+  // ---- normalise and store: lane (query, half h) holds head dims 32 j + 8 (r >> 2) + 4 h + (r & 3) ----
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (qg < p.Tq) {
+      if (h == 0) p.LSE[(long long)z * p.Tq + qg] = l > 0.f ? (m_run + log2f(l)) * 0.6931471805599453f : -INFINITY;
+      unsigned short* orow = p.O + b * p.o_b + hd * DH + (long long)qg * p.ldo;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const unsigned w0 = sc_f32_to_bf16(o[j][4 * r4] * inv) | ((unsigned)sc_f32_to_bf16(o[j][4 * r4 + 1] * inv) << 16);
+          const unsigned w1 = sc_f32_to_bf16(o[j][4 * r4 + 2] * inv) | ((unsigned)sc_f32_to_bf16(o[j][4 * r4 + 3] * inv) << 16);
+          *(uint2*)(orow + 32 * j + 8 * r4 + 4 * h) = make_uint2(w0, w1);
+        }
+    }
+  }
+}
+
 // Backward: one 512-thread workgroup per (batch, head) sweeping its 64-query tiles.  K and V of the head stay in LDS; per
 // tile S = Q K^T and dP = dO V^T are formed side by side in registers, P = exp(scale*S - lse) (masked), the dropout mask is
 // regenerated, dS = P * (dP - delta) * scale with delta = rowsum(dO * O); P~ (dropped P) and dS go to LDS as bf16 and feed
@@ -382,7 +570,10 @@ SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O
                             const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
                             const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(Q && K && V && O && LSE, "sc_attention_fwd: null pointer");
-  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && Tk <= TKMAX, "sc_attention_fwd: need 1 <= Tk <= %d (got %d)", TKMAX, Tk);
+  const bool stream_ok = (mask == nullptr || mask_q == 0) && ldo % 4 == 0 && o_b % 4 == 0 && (uintptr_t)O % 8 == 0 &&
+                         getenv("SC_ATTN_NO_STREAM") == nullptr;
+  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && (stream_ok || Tk <= TKMAX),
+               "sc_attention_fwd: a query-dependent mask needs 1 <= Tk <= %d (got %d)", TKMAX, Tk);
   SC_CHECK_ARG((long long)B * H <= 65535, "sc_attention_fwd: too many (batch, head) pairs");
   SC_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && q_b % 8 == 0 && kv_b % 8 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 &&
                    (uintptr_t)V % 16 == 0, "sc_attention_fwd: operands must be 16-byte aligned with strides multiple of 8");
@@ -394,6 +585,12 @@ SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O
   a.mask = mask; a.mask_b = mask_b; a.mask_q = mask_q; a.causal = causal;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldp = (Tk + 7) / 8 * 8; a.scale = scale; a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p);
   a.seed = seed; a.offset = offset;
+  if (stream_ok) {
+    const size_t smem_s = (size_t)3 * 2 * 64 * DH * sizeof(unsigned short);  // three 16 KB stages
+    hipLaunchKernelGGL(attn_fwd_stream_kernel, dim3(sc_cdiv(Tq, 128), B * H), dim3(256), smem_s, stream, a);
+    SC_LAUNCH_CHECK("attn_fwd_stream_kernel");
+    return SC_OK;
+  }
   const size_t smem = (size_t)(64 + 2 * TKMAX) * LDR * 2 + (size_t)64 * LDS_S * 4;
   SC_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(sc_cdiv(Tq, 64), B * H), dim3(512), smem, stream, a);

@@ -446,3 +446,39 @@ def test_fused_attention_matches_unfused(case, drop_p):
     finally:
         Fn.set_attention_probs(True)
         Fn.set_compute_dtype(None)
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(249, 249, False), (63, 700, False), (130, 130, True), (1, 5, False), (300, 64, False)])
+def test_streaming_attention_forward_through_the_c_abi(Tq, Tk, causal):
+    """sc_attention_fwd (streaming kernel: key masks, any Tk) on packed (B, T, H*64) bf16 buffers against torch fp32 attention
+    of the same bf16 values: output (bf16: 2^-8 relative on top of an f32 softmax over bf16-rounded P) and the saved row
+    logsumexp; an utterance whose keys are all masked gives zeros and -inf."""
+    from speechain_amd._lib import lib, stream
+
+    gen = torch.Generator().manual_seed(Tq * 1000 + Tk)
+    B, H, dh = 3, 2, 64
+    q = torch.randn(B, Tq, H * dh, generator=gen).bfloat16().cuda()
+    k = torch.randn(B, Tk, H * dh, generator=gen).bfloat16().cuda()
+    v = torch.randn(B, Tk, H * dh, generator=gen).bfloat16().cuda()
+    lens = torch.tensor([Tk, max(1, Tk // 2 + 1), 0]).cuda()  # full, ragged, nothing visible
+    m8 = (torch.arange(Tk, device="cuda")[None, :] < lens[:, None]).to(torch.uint8)[:, None, :].contiguous()
+    out = torch.empty(B, Tq, H * dh, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H, Tq, device="cuda")
+    scale = 1.0 / math.sqrt(dh)
+    lib.call("sc_attention_fwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(lse), B, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0),
+             k.stride(1), out.stride(0), out.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, stream())
+    qf, kf, vf = (t.float().view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    s_ = (qf @ kf.transpose(-1, -2)) * scale
+    ok = m8.bool()[:, :, None, :].expand(B, H, Tq, Tk).clone()
+    if causal:
+        ok &= (torch.arange(Tk, device="cuda")[None, :] <= torch.arange(Tq, device="cuda")[:, None])[None, None]
+    s_ = s_.masked_fill(~ok, float("-inf"))
+    ref_lse = torch.logsumexp(s_, -1)
+    pr = torch.nan_to_num(torch.softmax(s_, -1), nan=0.0)
+    ref = (pr @ vf).transpose(1, 2).reshape(B, Tq, H * dh)
+    assert torch.allclose(out.float(), ref, atol=2e-2, rtol=2e-2), float((out.float() - ref).abs().max())
+    got = lse.view(B, H, Tq)
+    fin = torch.isfinite(ref_lse)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert float((got[fin] - ref_lse[fin]).abs().max()) < 2e-3 if bool(fin.any()) else True
+    assert float(out[2].float().abs().max()) == 0.0
