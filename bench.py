@@ -177,12 +177,16 @@ class ASRTrainStepWorkload:
     def _capture(self):
         from speechain_amd import functional as Fn
 
+        # Every collective of the eager warm-up steps is complete before capture starts, and capture polices only THIS thread:
+        # RCCL's watchdog thread keeps polling completion events (hipEventQuery), which the default global capture mode
+        # rejects from any thread while a capture is open ("operation not permitted when stream is capturing").
+        self.reducer.wait()
         torch.cuda.synchronize()
         self.g_body = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_body):
+        with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
             self.loss = self._body()
         self.g_tail = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_tail):
+        with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
             self._tail()
         torch.cuda.synchronize()
 
@@ -203,7 +207,7 @@ class ASRTrainStepWorkload:
             self._capture()
         if graph:
             self.g_body.replay()
-            if self.world > 1:
+            if self.reducer.multi:
                 self.reducer.reduce_all_now()
             self.g_tail.replay()
             return self.loss
@@ -312,6 +316,11 @@ def cpu_baseline(seconds: float):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries print there too (RCCL writes a version banner to
+    # stdout when the process group comes up), so file descriptor 1 points at stderr until that line is written.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -319,9 +328,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (with RANK/WORLD_SIZE/MASTER_* from torch.distributed.run --nproc-per-node 1) runs the multi-rank code
+    # path -- RCCL process group, parameter broadcast, bucket all-reduces between the two hipGraphs, barriers, MAX over ranks --
+    # on a one-rank group: the rehearsal of the N > 1 launch that a single-GPU box allows.
+    force_dist = os.environ.get("BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if force_dist:
+            os.environ["SC_DDP_FORCE_COLLECTIVES"] = "1"
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
@@ -386,7 +401,10 @@ def main():
             line["config"]["prenet"] = PRENET_NOTE
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds, prenet_dims)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -13,6 +13,8 @@ Works with any process group (``nccl`` = RCCL on GPUs; ``gloo`` on CPU for the t
 """
 from typing import Iterable, List
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,6 +40,10 @@ class GradBucketReducer:
         ``speechain_amd.functional.GradSinks`` so the backward kernels write gradients in place."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # `multi`: run the collectives.  True for more than one rank -- or when a process group exists and the environment
+        # asks for it (SC_DDP_FORCE_COLLECTIVES=1): the multi-rank control flow on a one-rank group, which is how the N > 1
+        # path is rehearsed on a single GPU (bench.py BENCH_FORCE_DIST=1).
+        self.multi = self.world > 1 or (dist.is_initialized() and os.environ.get("SC_DDP_FORCE_COLLECTIVES", "0") == "1")
         params = [p for p in params if p.requires_grad]
         order = list(reversed(params))  # backward produces gradients roughly in reverse registration order
         group_of = {}
@@ -94,7 +100,7 @@ class GradBucketReducer:
     def _make_hook(self, bi):
         def hook(param):
             b = self.buckets[bi]
-            if self.use_sinks and self.world > 1:  # the slot must hold the gradient before the bucket is reduced
+            if self.use_sinks and self.multi:  # the slot must hold the gradient before the bucket is reduced
                 v = b["views"][b["index"][id(param)]]
                 if param.grad is not None and param.grad.data_ptr() != v.data_ptr():
                     v.copy_(param.grad)
@@ -105,7 +111,12 @@ class GradBucketReducer:
         return hook
 
     def _launch(self, b):
-        if self.world == 1:
+        if not self.multi:
+            return
+        if self.cuda and torch.cuda.is_current_stream_capturing():
+            # Backward is being captured into a hipGraph: a collective issued from a hook would fork the side stream off the
+            # capturing stream without a join ("capturing stream has unjoined work") and hand the RCCL watchdog a captured
+            # event.  The caller reduces every bucket eagerly after the replay instead (reduce_all_now).
             return
         if self.cuda:
             ev = torch.cuda.Event()
@@ -130,7 +141,7 @@ class GradBucketReducer:
 
     def broadcast_parameters(self, src: int = 0):
         """One-off parameter (and nothing else) broadcast at start-up."""
-        if self.world == 1:
+        if not self.multi:
             return
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.pg)
