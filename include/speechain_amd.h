@@ -103,6 +103,11 @@ int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, in
             long long ldaux, int aux_mode, float drop_p, const unsigned long long* seed, unsigned long long offset, int out_f32,
             int accumulate, hipStream_t stream);
 
+/* Measurement aid: id / name of the kernel the calling thread's last sc_gemm or sc_gemm_splitk dispatched (names as they appear
+ * in rocprofv3's kernel statistics).  bench.py attributes its per-launch HIP-event times to kernels with it. */
+int sc_gemm_last_kernel(void);
+const char* sc_gemm_kernel_name(int id);
+
 /* Split-K form for wgrad-shaped products (small M x N, long contraction K), bf16 operands, f32 output with ldc == N:
  * C (+)= alpha * opA opB^T.  `workspace` holds splitk partial M x N tiles that a second deterministic kernel sums.
  * colsum (nullable, needs ta): colsum[m] (+)= sum_k A[k][m], the column sums of the transposed A over the contraction --

@@ -51,6 +51,8 @@ class _Lib:
         # current stream tightly around the launch; None = off (the default, zero overhead)
         self.timing = None
         self.flop_log = None  # optional list receiving 2*M*N*K*batch of every sc_gemm call (bench.py roofline)
+        self.kernel_log = None  # optional list receiving sc_gemm_last_kernel() after every sc_gemm / sc_gemm_splitk call
+        self.shape_log = None  # optional list receiving (M, N, K, batch) of the same calls
 
     def load(self):
         if self._dll is not None:
@@ -84,6 +86,10 @@ class _Lib:
             rc = getattr(dll, name)(*args)
             e1.record()
             rec.append((e0, e1))
+            if self.kernel_log is not None and name in ("sc_gemm", "sc_gemm_splitk"):
+                self.kernel_log.append(dll.sc_gemm_last_kernel())
+                if self.shape_log is not None:
+                    self.shape_log.append((args[6], args[7], args[8], args[12] * args[13]) if name == "sc_gemm" else (args[5], args[6], args[7], 1))
         else:
             rc = getattr(dll, name)(*args)
         if rc != 0:

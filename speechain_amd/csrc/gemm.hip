@@ -1194,6 +1194,28 @@ int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const ch
 
 }  // namespace
 
+// Which kernel the last sc_gemm / sc_gemm_splitk call of this thread dispatched (bench.py attributes its per-launch HIP-event
+// times to kernels with it, so that its roofline line names a row of the rocprofv3 kernel statistics).
+static thread_local int g_last_gemm_kernel = 0;
+static const char* const kGemmKernelNames[] = {
+    "none",
+    "gemm_bf16_nt_dma_kernel<2, 2, 2>",
+    "gemm_bf16_nt_dma_kernel<2, 4, 4>",
+    "gemm_bf16_kernel<false, false>",
+    "gemm_bf16_kernel<false, true>",
+    "gemm_bf16_kernel<true, false>",
+    "gemm_bf16_kernel<true, true>",
+    "gemm_f32_kernel",
+    "gemm_bf16_kernel<true, true> (split-K) + splitk_reduce_kernel",
+    "gemm_bf16_tn_dma_splitk_kernel + splitk_reduce_kernel",
+    "gemm_bf16_kernel (split-K, other layout) + splitk_reduce_kernel",
+    "gemm_bf16_nt_dma_kernel<2, 2, 1>",
+};
+SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+SC_API const char* sc_gemm_kernel_name(int id) {
+  return (id >= 0 && id < (int)(sizeof(kGemmKernelNames) / sizeof(kGemmKernelNames[0]))) ? kGemmKernelNames[id] : "unknown";
+}
+
 // dtype: 0 = f32, 1 = bf16 (A, B, aux, pre_out and -- unless out_f32 -- C share it).
 SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
                    long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1,
@@ -1233,14 +1255,23 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
     if (!ta && !tb && a.a_vec && a.b_vec && (K % BK16 == 0) && K >= 2 * BK16) {
       // 256 x 256 tiles when they still give every CU work, else 128 x 128
       const long long big = (long long)sc_cdiv(M, 256) * sc_cdiv(N, 256) * nb;
-      if (big >= 160) return launch_dma<2, 4, 4>(a, nb, stream);
+      // Few 128 x 128 tiles (the decoder-sized products, M ~ 2000: 64 .. 250 workgroups on 256 CUs): 64 x 128 tiles double the
+      // number of waves.  Measured on M = 2016: N = K = 512 18.0 -> 13.9 us, K = 2048 33.4 -> 27.8 us, K = 1536 25.2 -> 21.4 us
+      // (DESIGN.md section 6).  [Tried and rejected: 128 x 128 instead of 256 x 256 tiles for the launches with a VALU-heavy
+      // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
+      const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
+      if (big >= 160) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
+      if (t128 < 256) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
+      g_last_gemm_kernel = 1;
       return launch_dma<2, 2, 2>(a, nb, stream);
     }
+    g_last_gemm_kernel = 3 + (ta ? 2 : 0) + (tb ? 1 : 0);
     if (!ta && !tb) return launch(gemm_bf16_kernel<false, false>, a, nb, stream, "gemm_bf16<NT>");
     if (!ta && tb) return launch(gemm_bf16_kernel<false, true>, a, nb, stream, "gemm_bf16<NN>");
     if (ta && !tb) return launch(gemm_bf16_kernel<true, false>, a, nb, stream, "gemm_bf16<TT>");
     return launch(gemm_bf16_kernel<true, true>, a, nb, stream, "gemm_bf16<TN>");
   }
+  g_last_gemm_kernel = 7;
   if (!ta && !tb) return launch(gemm_f32_kernel<false, false>, a, nb, stream, "gemm_f32<NT>");
   if (!ta && tb) return launch(gemm_f32_kernel<false, true>, a, nb, stream, "gemm_f32<NN>");
   if (ta && !tb) return launch(gemm_f32_kernel<true, false>, a, nb, stream, "gemm_f32<TT>");
@@ -1279,6 +1310,7 @@ SC_API int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C
   int rc;
   const bool tn_dma = ta && tb && a.a_vec && a.b_vec && K % BK16 == 0 && M % 8 == 0 && N % 8 == 0 && M >= 8 && N >= 8 &&
                       getenv("SC_GEMM_TN_DMA") != nullptr;  // opt-in: measured 1.3 % slower per train step than the register-staged kernel
+  g_last_gemm_kernel = tn_dma ? 9 : (ta && tb ? 8 : 10);
   if (tn_dma) {
     constexpr size_t smem = (size_t)4 * 2 * BM * BK16 * sizeof(unsigned short);  // four 16 KB stages
     static_assert(smem >= (size_t)16 * 128 * sizeof(float) && smem >= (size_t)4 * 32 * STG_LD * sizeof(float), "stages must cover the staging tiles");
