@@ -1170,8 +1170,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
-      f32x4 s = *(const f32x4*)(slabs + i);
-      for (int k = 1; k < S; ++k) s += *(const f32x4*)(slabs + (long long)k * n + i);
+      // eight slice loads in flight per thread (the slabs sit in L2 / Infinity Cache: the kernel is latency-bound, and a loop
+      // with a run-time trip count would keep one load in flight); the summation order stays k = 0, 1, 2, ...
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < S; k0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = (k0 + u < S) ? *(const f32x4*)(slabs + (long long)(k0 + u) * n + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
       if (accumulate) s += *(const f32x4*)(out + i);
       *(f32x4*)(out + i) = s;
     } else {
@@ -1255,13 +1264,14 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
     if (!ta && !tb && a.a_vec && a.b_vec && (K % BK16 == 0) && K >= 2 * BK16) {
       // 256 x 256 tiles when they still give every CU work, else 128 x 128
       const long long big = (long long)sc_cdiv(M, 256) * sc_cdiv(N, 256) * nb;
-      // Few 128 x 128 tiles (the decoder-sized products, M ~ 2000: 64 .. 250 workgroups on 256 CUs): 64 x 128 tiles double the
+      // Few 128 x 128 tiles (the decoder-sized products, M ~ 2000: 64 .. 192 workgroups on 256 CUs): 64 x 128 tiles double the
       // number of waves.  Measured on M = 2016: N = K = 512 18.0 -> 13.9 us, K = 2048 33.4 -> 27.8 us, K = 1536 25.2 -> 21.4 us
-      // (DESIGN.md section 6).  [Tried and rejected: 128 x 128 instead of 256 x 256 tiles for the launches with a VALU-heavy
+      // (DESIGN.md section 6).  At 252 tiles (M = 7968, N = 512) they do not pay: K = 1536 26.4 -> 30.9 us, K = 2048 44.8 -> 45.5 us,
+      // K = 512 21.1 -> 20.3 us -- hence the threshold of 192.  [Tried and rejected: 128 x 128 instead of 256 x 256 tiles for the launches with a VALU-heavy
       // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       if (big >= 160) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
-      if (t128 < 256) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
+      if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
       g_last_gemm_kernel = 1;
       return launch_dma<2, 2, 2>(a, nb, stream);
     }
