@@ -106,7 +106,7 @@ PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + LeakyReLU + Linear, as th
 
 
 class ASRTrainStepWorkload:
-    """BASELINE.json configs[2] driven from waveforms: frontend -> SpecAugment -> conv2d prenet (torch/MIOpen, outside the named
+    """BASELINE.json configs[2] driven from waveforms: frontend -> global mean/std normalisation -> SpecAugment -> conv2d prenet (torch/MIOpen, outside the named
     path; channels from --prenet-dims) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip ->
     Adam (Noam), bf16 compute."""
 
@@ -115,18 +115,21 @@ class ASRTrainStepWorkload:
     def __init__(self, device, seed, world, prenet_dims=(64, 64)):
         self.prenet_dims = tuple(prenet_dims)
         self.name = ("ASR transformer-base train step (12enc/6dec d512 h8 ffn2048 V5000, bf16) from 32x10s@16kHz waveforms: frontend + "
-                     f"specaug + conv2d-prenet{list(self.prenet_dims)} + encoder + decoder + 0.7CE/0.3CTC + backward + clip + Adam "
+                     f"global mean/std normalisation + specaug + conv2d-prenet{list(self.prenet_dims)} + encoder + decoder + "
+                     "0.7CE/0.3CTC + backward + clip + Adam "
                      "(BASELINE configs[2])")
         from speechain_amd import functional as Fn
         from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
         from speechain_amd.harness import ASRTransformer, Conv2dSubsample
         from speechain_amd.module.augment.specaug import SpecAugment
         from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
+        from speechain_amd.module.norm.feat_norm import FeatureNormalization
 
         Fn.set_compute_dtype(torch.bfloat16)
         Fn.set_attention_probs(False)  # the train step never reads the attention maps: fused attention, no score tensors in HBM
         torch.manual_seed(0)  # identical initial weights on every rank
         self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
+        self.norm = FeatureNormalization(input_size=80).to(device).train()  # the recipes' `normalize: True` (global mean / std)
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
         self.prenet = Conv2dSubsample(80, self.prenet_dims, 512).to(device).train()
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
@@ -199,6 +202,7 @@ class ASRTrainStepWorkload:
         self.lr.fill_(2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5)
         with torch.no_grad():  # frontend + SpecAugment stay eager: SpecAugment's index draws read the lengths on the host
             feat, flen = self.fe(self.wave, self.lens)
+            feat, flen = self.norm(feat, flen, epoch=1)  # module/encoder/asr.py:111-115: between the frontend and SpecAugment
             feat, flen = self.sa(feat, flen)
             self.feat.copy_(feat)
             self.flen.copy_(flen)
@@ -286,7 +290,7 @@ def pmc_traffic(kernel: str):
 
 
 def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
-    """The oracle's ASR step (frontend -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
+    """The oracle's ASR step (frontend -> normalisation -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
     on a bounded sample: ~`seconds` of steps over 4 of the 32 utterances (same per-utterance shapes), scaled to utterances/s."""
     from oracle import cpu_ref as R
     from speechain_amd.harness import ASRTransformer, Conv2dSubsample
@@ -304,8 +308,11 @@ def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
     text, text_len = synth_text(0, "cpu")
     wave, lens, text, text_len = wave[:nb].squeeze(-1), lens[:nb], text[:nb], text_len[:nb]
 
+    norm = R.FeatureNormalization()
+
     def one():
         feat, flen = R.speech2mel(wave, lens, **ASR_FRONTEND)
+        feat, flen = norm(feat, flen, epoch=1)
         d = R.specaug_draw(flen, nb, 80, **SPECAUG)
         feat = R.specaug_apply(feat, flen, d)
         x, xlen = prenet(feat, flen)

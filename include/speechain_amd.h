@@ -72,6 +72,18 @@ int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, int B, 
 int sc_mel_log_fwd(const float* spec, long long N, int NB, const float* melw, const int* band_lo, const int* band_hi,
                    int n_mels, float clamp, int logging, float log_div, float* out, hipStream_t stream);
 
+/* ---- feature normalisation (speechain/module/norm/feat_norm.py) ------------------------------------------------------------
+ * sc_featnorm_stats: per-utterance statistics over the valid frames feat[b][:feat_len[b]] of a (B, T, F) f32 tensor with strides
+ * (stride_b, stride_t, 1): mean (B, F) and the unbiased standard deviation clamped from below (B, F) -- the Python loops at
+ * feat_norm.py:115-133.  Either output may be null.  One frame gives std = NaN and no frame mean = NaN, as torch does.
+ * sc_featnorm_apply: out = (feat - mean) / std over the WHOLE padded tensor (feat_norm.py:137-139, 280-299, 322-331); a
+ * statistics stride of 0 means one shared (F,) vector, otherwise one vector per utterance; a null vector skips that step. */
+int sc_featnorm_stats(const float* feat, long long stride_b, long long stride_t, const long long* feat_len, int B, int T, int F,
+                      float clamp, float* mean, float* std, hipStream_t stream);
+int sc_featnorm_apply(const float* feat, float* out, long long stride_b, long long stride_t, long long out_stride_b,
+                      long long out_stride_t, int B, int T, int F, const float* mean, long long mean_stride_b, const float* std,
+                      long long std_stride_b, hipStream_t stream);
+
 /* ---- SpecAugment -----------------------------------------------------------------------------------------
  * Replaces SpecAugment.forward after its random draws (speechain/module/augment/specaug.py:111-124 time warp,
  * :160-199 mask construction, :202-204 masked_fill).  in/out (B, T, F) f32.  warp_center < 0 disables the warp;

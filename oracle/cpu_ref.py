@@ -541,3 +541,108 @@ def asr_forward_loss(feat: Tensor, feat_len: Tensor, text: Tensor, text_len: Ten
     ctc = ctc_loss(ctc_logits, feat_len, text, text_len)
     w = cfg.get("ctc_weight", 0.3)
     return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=(1 - w) * ce + w * ctc)
+
+
+# ---- feature normalisation (row f1) --------------------------------------------------------------------------------------
+class FeatureNormalization:
+    """Stateful restatement of speechain/module/norm/feat_norm.py (FeatureNormalization.forward :78-338,
+    register_mean_std_batch :452-509, update_aver_mean_std :511-531, recover :533-604), single process.
+
+    Mirrored on purpose: statistics over the valid frames ``feat[i][:feat_len[i]]`` with torch's unbiased std, clamped at
+    ``clamp`` (:115-133); the normalisation is applied to the WHOLE padded tensor (:137-139, :322-331); the running
+    statistics are re-created on every update and weighted 1 / (number of batches seen), the counter restarting at 1 whenever
+    ``epoch`` is None (:472-476) and frozen once ``epoch > max_epoch_num`` (:477-480, :483); the average over groups takes
+    every buffer whose name ends in ``_mean`` / ``_std`` -- including the previous average itself (:519-528).
+    ``mean_norm=False`` with the global / group types raises in the reference (:475 reads ``curr_aver_mean.device`` of None);
+    here it raises a ValueError."""
+
+    def __init__(self, norm_type: str = "global", mean_norm: bool = True, std_norm: bool = True, clamp: float = 1e-10,
+                 max_epoch_num: int = 4):
+        if norm_type not in ("utterance", "batch", "group", "global"):
+            raise ValueError(f"norm_type can only be one of 'utterance', 'batch', 'group', 'global', but got {norm_type}")
+        if not mean_norm and norm_type in ("global", "group"):
+            raise ValueError("mean_norm=False is broken in the reference for the global / group types (feat_norm.py:475)")
+        self.norm_type, self.mean_norm, self.std_norm = norm_type, mean_norm, std_norm
+        self.clamp, self.max_epoch_num = clamp, max_epoch_num
+        self.training = True
+        self.buffers = {}  # insertion-ordered, like nn.Module._buffers
+
+    def _register(self, mean, std, prefix, epoch):
+        b = self.buffers
+        if epoch is None or f"{prefix}_batch" not in b:
+            b[f"{prefix}_batch"] = torch.tensor([1], dtype=torch.int64)
+        elif epoch <= self.max_epoch_num:
+            b[f"{prefix}_batch"] = b[f"{prefix}_batch"] + 1
+        if epoch is None or epoch <= self.max_epoch_num:
+            w = 1 / b[f"{prefix}_batch"]
+            if self.mean_norm:
+                b[f"{prefix}_mean"] = mean if f"{prefix}_mean" not in b else w * mean + (1 - w) * b[f"{prefix}_mean"]
+            if self.std_norm:
+                b[f"{prefix}_std"] = std if f"{prefix}_std" not in b else w * std + (1 - w) * b[f"{prefix}_std"]
+
+    def _update_aver(self, epoch):
+        if epoch is None or epoch <= self.max_epoch_num:
+            means = [v for k, v in self.buffers.items() if k.endswith("_mean")]
+            stds = [v for k, v in self.buffers.items() if k.endswith("_std")]
+            am, as_ = None, None
+            for v in means:
+                am = v.clone() if am is None else am + v
+            for v in stds:
+                as_ = v.clone() if as_ is None else as_ + v
+            self.buffers["aver_mean"] = am / len(means)
+            self.buffers["aver_std"] = as_ / len(stds)
+
+    def __call__(self, feat: Tensor, feat_len: Tensor, group_ids=None, epoch: int = None):
+        squeeze = feat.dim() == 2
+        if squeeze:
+            feat = feat.unsqueeze(-1)
+        B = feat.size(0)
+        means = torch.stack([feat[i][: feat_len[i]].mean(dim=0) for i in range(B)]) if self.mean_norm else None
+        stds = torch.clamp(torch.stack([feat[i][: feat_len[i]].std(dim=0) for i in range(B)]), min=self.clamp) if self.std_norm else None
+        if self.norm_type == "utterance":
+            feat = feat - means.unsqueeze(1) if means is not None else feat
+            feat = feat / stds.unsqueeze(1) if stds is not None else feat
+        elif self.norm_type == "group" and isinstance(group_ids, Tensor):
+            if self.training:
+                order = []
+                for g in group_ids.tolist():
+                    if g not in order:
+                        order.append(g)
+                for g in order:
+                    sel = group_ids == g
+                    self._register(means[sel].mean(dim=0) if means is not None else None,
+                                   stds[sel].mean(dim=0) if stds is not None else None, g, epoch)
+                self._update_aver(epoch)
+            feat = feat.clone()
+            for i in range(B):
+                g = int(group_ids[i])
+                if self.mean_norm:
+                    feat[i] -= self.buffers.get(f"{g}_mean", self.buffers["aver_mean"])
+                if self.std_norm:
+                    feat[i] /= self.buffers.get(f"{g}_std", self.buffers["aver_std"])
+        else:
+            bm = means.mean(dim=0) if (self.training and means is not None) else None
+            bs = stds.mean(dim=0) if (self.training and stds is not None) else None
+            if self.norm_type == "batch":
+                if self.training:
+                    feat = feat - bm if bm is not None else feat
+                    feat = feat / bs if bs is not None else feat
+                else:
+                    feat = feat - means.unsqueeze(1) if means is not None else feat
+                    feat = feat / stds.unsqueeze(1) if stds is not None else feat
+            else:
+                if self.norm_type == "group" and not isinstance(group_ids, (str, int)):
+                    raise AssertionError("group-level normalisation of a whole batch needs group_ids as a string or integer")
+                prefix = "global" if self.norm_type == "global" else group_ids
+                if self.training:
+                    self._register(bm, bs, prefix, epoch)
+                feat = feat - self.buffers[f"{prefix}_mean"] if means is not None else feat
+                feat = feat / self.buffers[f"{prefix}_std"] if stds is not None else feat
+        return (feat.squeeze(-1) if squeeze else feat), feat_len
+
+    def recover(self, feat: Tensor, group_ids=None) -> Tensor:
+        """feat_norm.py:533-604 for the global type and whole-batch groups."""
+        assert self.norm_type not in ("utterance", "batch")
+        prefix = "global" if self.norm_type == "global" else str(group_ids)
+        feat = feat * self.buffers[f"{prefix}_std"] if self.std_norm else feat
+        return feat + self.buffers[f"{prefix}_mean"] if self.mean_norm else feat

@@ -21,6 +21,7 @@ OVERLAY = {
     "speechain.module.frontend.speech2mel": "speechain_amd.module.frontend.speech2mel",
     "speechain.module.frontend.delta_feat": "speechain_amd.module.frontend.delta_feat",
     "speechain.module.augment.specaug": "speechain_amd.module.augment.specaug",
+    "speechain.module.norm.feat_norm": "speechain_amd.module.norm.feat_norm",
     "speechain.module.transformer.pos_enc": "speechain_amd.module.transformer.pos_enc",
     "speechain.module.transformer.attention": "speechain_amd.module.transformer.attention",
     "speechain.module.transformer.feed_forward": "speechain_amd.module.transformer.feed_forward",

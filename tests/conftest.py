@@ -24,6 +24,9 @@ def load_golden(name):
         a = z[k]
         if a.dtype == np.float16:
             a = a.astype(np.float32)
+        if a.dtype.kind in "US":  # arrays of names (e.g. state-dict keys) stay Python strings
+            out[k] = [str(x) for x in a.reshape(-1)]
+            continue
         out[k] = torch.from_numpy(a) if a.shape != () else torch.tensor(a.item())
     return out
 

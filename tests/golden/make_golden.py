@@ -11,6 +11,11 @@ What is stubbed and why:
     mel matrix values are "parity unpinned"; everything downstream of them is the reference's own code.
   * ``GPUtil`` (only imported by utilbox/import_util.py) is stubbed with an empty module.
 
+  * g8 (FeatureNormalization): feat_norm.py:474 creates its batch counter with ``.cuda(device=...)`` even for CPU inputs; this
+    container has no GPU, so while g8 runs ``torch.Tensor.cuda`` returns the tensor itself.  Arithmetic is untouched.  The
+    module's DDP branch (all_gather over ranks) cannot run here; tests check the 2-rank result against this single-process
+    behaviour on the concatenated batch, which is what the reference's gather formulas reduce to.
+
 Outputs are data only (inputs, seeds' products, expected outputs) as ``.npz``; no reference text.
 """
 import os
@@ -399,7 +404,85 @@ def g7_harness():
     save("g7_harness", **out)
 
 
+def g8_featnorm():
+    """FeatureNormalization (module/norm/feat_norm.py:78-338, 452-509): every norm_type, training sequences with the running
+    statistics (epoch gating, epoch=None), evaluation, mean-only / std-only, 2-D input, tensor / int group ids."""
+    from speechain.module.norm.feat_norm import FeatureNormalization
+
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        gen = torch.Generator().manual_seed(80)
+        B, T, F = 4, 13, 5
+        out = {}
+        batches = []
+        for j in range(5):
+            feat = torch.randn(B, T, F, generator=gen) * (1.0 + 0.5 * j) + 0.3 * j
+            flen = torch.tensor([13, 9, 2, 6]) if j % 2 == 0 else torch.tensor([7, 13, 11, 3])
+            for i in range(B):
+                feat[i, flen[i]:] = 0
+            batches.append((feat, flen))
+            out[f"feat{j}"], out[f"len{j}"] = feat, flen
+
+        def bufs(m, tag):
+            for k, v in m.named_buffers():
+                out[f"{tag}.buf.{k}"] = v.clone().float() if v.dtype != torch.int64 else v.clone()
+
+        # utterance / batch
+        m = FeatureNormalization(input_size=F, norm_type="utterance").train()
+        out["utt.y"] = m(batches[0][0].clone(), batches[0][1].clone())[0]
+        m = FeatureNormalization(input_size=F, norm_type="batch").train()
+        out["batch.train.y"] = m(batches[0][0].clone(), batches[0][1].clone())[0]
+        out["batch.eval.y"] = m.eval()(batches[1][0].clone(), batches[1][1].clone())[0]
+        # global (the recipes' `normalize: True`): epochs 1,1,2 accumulate, epoch 5 is frozen (max_epoch_num = 4), then eval
+        m = FeatureNormalization(input_size=F).train()
+        for step, (j, ep) in enumerate([(0, 1), (1, 1), (2, 2), (3, 5)]):
+            out[f"global.s{step}.y"] = m(batches[j][0].clone(), batches[j][1].clone(), epoch=ep)[0]
+            bufs(m, f"global.s{step}")
+        out["global.eval.y"] = m.eval()(batches[4][0].clone(), batches[4][1].clone())[0]
+        out["global.recover"] = m.recover(out["global.eval.y"].clone())
+        sd = m.state_dict()
+        out["global.sd_keys"] = np.array(sorted(sd.keys()))
+        # epoch=None: the counter restarts at every call
+        m = FeatureNormalization(input_size=F).train()
+        for step in range(2):
+            out[f"global_noepoch.s{step}.y"] = m(batches[step][0].clone(), batches[step][1].clone())[0]
+            bufs(m, f"global_noepoch.s{step}")
+        # mean only / std only
+        m = FeatureNormalization(input_size=F, std_norm=False).train()
+        out["meanonly.y"] = m(batches[0][0].clone(), batches[0][1].clone(), epoch=1)[0]
+        # (mean_norm=False with the global / group types raises in the reference itself: feat_norm.py:475 reads
+        #  curr_aver_mean.device of None -- so std-only is recorded for the utterance type, where it works)
+        m = FeatureNormalization(input_size=F, norm_type="utterance", mean_norm=False, clamp=0.5).train()
+        out["stdonly.y"] = m(batches[0][0].clone(), batches[0][1].clone())[0]
+        # 2-D input
+        m = FeatureNormalization(input_size=1, norm_type="utterance").train()
+        out["twod.y"] = m(batches[0][0][:, :, 0].clone(), batches[0][1].clone())[0]
+        # group: one id for the whole batch (int), then per-utterance ids, then an unseen id at evaluation
+        m = FeatureNormalization(input_size=F, norm_type="group").train()
+        out["group_int.s0.y"] = m(batches[0][0].clone(), batches[0][1].clone(), group_ids=7, epoch=1)[0]
+        out["group_int.s1.y"] = m(batches[1][0].clone(), batches[1][1].clone(), group_ids=7, epoch=1)[0]
+        bufs(m, "group_int.s1")
+        m = FeatureNormalization(input_size=F, norm_type="group").train()
+        ids0, ids1 = torch.tensor([3, 5, 3, 5]), torch.tensor([5, 5, 3, 9])
+        out["group_ids0"], out["group_ids1"] = ids0, ids1
+        out["group_t.s0.y"] = m(batches[0][0].clone(), batches[0][1].clone(), group_ids=ids0, epoch=1)[0]
+        out["group_t.s1.y"] = m(batches[1][0].clone(), batches[1][1].clone(), group_ids=ids1, epoch=1)[0]
+        bufs(m, "group_t.s1")
+        ids2 = torch.tensor([3, 11, 9, 5])  # 11 was never seen: average statistics
+        out["group_ids2"] = ids2
+        out["group_t.eval.y"] = m.eval()(batches[2][0].clone(), batches[2][1].clone(), group_ids=ids2)[0]
+    finally:
+        torch.Tensor.cuda = real_cuda
+    save("g8_featnorm", **out)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     g1_frontend()
     g2_specaug()
     g3_posenc()
@@ -407,3 +490,4 @@ if __name__ == "__main__":
     g5_stacks()
     g6_losses()
     g7_harness()
+    g8_featnorm()

@@ -217,3 +217,62 @@ def test_harness(golden):
                                          P["decoder.trfm_layers.1.encdec_att.k_layer.bias"], P["ctc_layer.linear.weight"]])
     for a, k in zip(gs, ("g_enc0_q", "g_embed", "g_dec1_encdec_kb", "g_ctc_w")):
         close(a, g[k], atol=1e-4, rtol=1e-3)
+
+
+# ---- g8: FeatureNormalization (row f1) -------------------------------------------------------------------------------------
+def _fn_batches(g):
+    return [(g[f"feat{j}"].clone(), g[f"len{j}"].clone()) for j in range(5)]
+
+
+def _fn_close(a, b, what):
+    assert a.shape == b.shape, what
+    assert torch.allclose(a, b, atol=1e-6, rtol=1e-5), (what, float((a - b).abs().max()))
+
+
+def _fn_bufs(g, tag, m):
+    for k, v in m.buffers.items():
+        ref = g[f"{tag}.buf.{k}"]
+        if v.dtype == torch.int64:
+            assert torch.equal(v, ref.to(torch.int64)), (tag, k)
+        else:
+            _fn_close(v, ref, f"{tag}.{k}")
+    assert {k for k in g.keys() if k.startswith(tag + ".buf.")} == {f"{tag}.buf.{k}" for k in m.buffers}
+
+
+def test_feature_normalization_oracle_vs_reference(golden):
+    g = golden("g8_featnorm")
+    bt = _fn_batches(g)
+    m = R.FeatureNormalization("utterance")
+    _fn_close(m(*bt[0])[0], g["utt.y"], "utterance")
+    m = R.FeatureNormalization("batch")
+    _fn_close(m(*bt[0])[0], g["batch.train.y"], "batch train")
+    m.training = False
+    _fn_close(m(*bt[1])[0], g["batch.eval.y"], "batch eval")
+    m = R.FeatureNormalization()  # global: the recipes' `normalize: True`
+    for step, (j, ep) in enumerate([(0, 1), (1, 1), (2, 2), (3, 5)]):
+        _fn_close(m(*bt[j], epoch=ep)[0], g[f"global.s{step}.y"], f"global step {step}")
+        _fn_bufs(g, f"global.s{step}", m)
+    m.training = False
+    y = m(*bt[4])[0]
+    _fn_close(y, g["global.eval.y"], "global eval")
+    _fn_close(m.recover(y), g["global.recover"], "recover")
+    assert sorted(m.buffers) == sorted(str(k) for k in g["global.sd_keys"])
+    m = R.FeatureNormalization()
+    for step in range(2):
+        _fn_close(m(*bt[step])[0], g[f"global_noepoch.s{step}.y"], f"no-epoch step {step}")
+        _fn_bufs(g, f"global_noepoch.s{step}", m)
+    _fn_close(R.FeatureNormalization(std_norm=False)(*bt[0], epoch=1)[0], g["meanonly.y"], "mean only")
+    _fn_close(R.FeatureNormalization("utterance", mean_norm=False, clamp=0.5)(*bt[0])[0], g["stdonly.y"], "std only")
+    _fn_close(R.FeatureNormalization("utterance")(bt[0][0][:, :, 0], bt[0][1])[0], g["twod.y"], "2-D input")
+    m = R.FeatureNormalization("group")
+    _fn_close(m(*bt[0], group_ids=7, epoch=1)[0], g["group_int.s0.y"], "group int 0")
+    _fn_close(m(*bt[1], group_ids=7, epoch=1)[0], g["group_int.s1.y"], "group int 1")
+    _fn_bufs(g, "group_int.s1", m)
+    m = R.FeatureNormalization("group")
+    _fn_close(m(*bt[0], group_ids=g["group_ids0"], epoch=1)[0], g["group_t.s0.y"], "group tensor 0")
+    _fn_close(m(*bt[1], group_ids=g["group_ids1"], epoch=1)[0], g["group_t.s1.y"], "group tensor 1")
+    _fn_bufs(g, "group_t.s1", m)
+    m.training = False
+    _fn_close(m(*bt[2], group_ids=g["group_ids2"])[0], g["group_t.eval.y"], "group tensor eval (unseen id -> average)")
+    with pytest.raises(ValueError):
+        R.FeatureNormalization("global", mean_norm=False)
