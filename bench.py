@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
     ap.add_argument("--prenet-dims", default="64,64",
                     help="conv channels of the Conv2d prenet in front of the encoder (outside the named hot path, plain torch/MIOpen). "
-                         "64,64 = the reference module's default; 512,512 = what the LibriSpeech transformer recipes set (conv_dims = d_model)")
+                         "64,64 = the transformer-wide recipes (and the module default); 512,512 = the transformer-large recipes (conv_dims = d_model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -84,6 +84,7 @@ class FrontendWorkload:
         return sum(a.elapsed_time(b) for a, b in self.ev) / max(1, len(self.ev))
 
 
+NAMED_PATH_FLOPS_PER_STEP = 2.54e12
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak of MI355X (MI355X_MICROARCH.md)
 ASR_MODEL = dict(d_model=512, num_heads=8, enc_layers=12, dec_layers=6, fdfwd_dim=2048, vocab_size=5000, dropout=0.1,
                  activation="GELU", label_smoothing=0.2, ctc_weight=0.3)
@@ -98,11 +99,13 @@ def synth_text(seed: int, device, vocab: int = 5000):
     return text.to(device), torch.full((BATCH,), TEXT_LEN, dtype=torch.int64, device=device)
 
 
-PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + LeakyReLU + Linear, as the recipes configure it) is OUTSIDE the named hot path "
-               "and runs on stock torch/MIOpen in fp32. conv_dims [64,64] is the reference module's default; the LibriSpeech "
-               "transformer recipes set conv_dims = d_model = [512,512] (recipes/asr/librispeech/train-clean-100/exp_cfg/"
-               "100-bpe5k_transformer-large_lr2e-3.yaml:197-206), whose convolutions cost more FLOPs than the 12-layer encoder "
-               "(SURVEY.md section 2 row 9, section 8f #2): run --prenet-dims 512,512 for the full-recipe step")
+PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + activation + Linear) is OUTSIDE the named hot path and runs on stock torch/MIOpen in "
+               "fp32. Both channel settings occur in the reference's ASR recipes for this d512/h8/ffn2048 transformer: conv_dims [64,64] "
+               "in the transformer-wide_ctc_perturb recipes (recipes/asr/librispeech/train-960/exp_cfg/960-bpe5k_transformer-wide_ctc_"
+               "perturb.yaml:205-213; also the module default), conv_dims = d_model = [512,512] in the transformer-large recipes "
+               "(.../train-clean-100/exp_cfg/100-bpe5k_transformer-large_lr2e-3.yaml:197-206), whose convolutions cost more FLOPs than "
+               "the 12-layer encoder. SURVEY.md section 8d: [64,64] primary (keeps the step dominated by the named path), [512,512] "
+               "secondary: run --prenet-dims 512,512 (measured: profiles/r01_train_step_bench_prenet512.json)")
 
 
 class ASRTrainStepWorkload:
@@ -272,6 +275,7 @@ class ASRTrainStepWorkload:
                 "all_gemm_launches": {"achieved": round(agg, 2), "frac": round(agg / MFMA_BF16_PEAK_TFLOPS, 5), "launches_timed": n,
                                       "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops},
                 "by_kernel": by_kernel,
+                "step_named_path": None,  # filled by main(): SURVEY 8d's 2.54 TFLOP of the named path / the measured step time
                 "note": "one timed step runs eagerly with HIP events around every sc_gemm/sc_gemm_splitk launch (the other steps "
                         "replay hipGraphs); `kernel` is the single GEMM kernel with the largest summed time in that step, achieved = its "
                         "2*M*N*K*batch flops / its event time; the split-K entries of by_kernel time two launches (product + "
@@ -447,6 +451,12 @@ def main():
         }
         if args.workload == "asr_train_step":
             line["config"]["prenet"] = PRENET_NOTE
+            step_s = elapsed / args.steps
+            tf = NAMED_PATH_FLOPS_PER_STEP / step_s / 1e12
+            roof["step_named_path"] = {"flops_per_step": NAMED_PATH_FLOPS_PER_STEP, "achieved": round(tf, 2),
+                                       "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5),
+                                       "note": "SURVEY.md section 8d config 3: 848 GFLOP forward x 3 of the named path (encoder, decoder, "
+                                               "heads; prenet excluded) per 32-utterance step / measured step time / dense bf16 peak"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds, prenet_dims)
         sys.stdout.flush()

@@ -32,9 +32,10 @@ class Embed(torch.nn.Module):
 class Conv2dSubsample(torch.nn.Module):
     """Stand-in for the recipe's Conv2dPrenet (module/prenet/conv2d.py:164-280: two Conv2d(k3, s2, no bias) + BatchNorm2d +
     LeakyReLU as the transformer recipes configure it, then Linear) -- OUTSIDE the named hot path, so it is plain
-    torch/MIOpen here.  (B, T, F) -> (B, T', d).  NOTE conv_dims: (64, 64) is the reference module's default; the LibriSpeech
-    transformer recipes set conv_dims = (d_model, d_model) = (512, 512), which costs 29 ms of MIOpen time per 32-utterance step
-     -- pass it explicitly (bench.py --prenet-dims 512,512) to time the full recipe model."""
+    torch/MIOpen here.  (B, T, F) -> (B, T', d).  NOTE conv_dims: both settings occur in the
+    reference's recipes for this transformer: (64, 64) in transformer-wide_ctc_perturb (and as the module default), (d_model,
+    d_model) = (512, 512) in transformer-large, where the prenet costs 29 ms of MIOpen time per 32-utterance step (DESIGN.md
+    section 6; bench.py --prenet-dims 512,512)."""
 
     def __init__(self, feat_dim: int = 80, conv_dims=(64, 64), d_model: int = 512):
         super().__init__()
