@@ -1,8 +1,10 @@
 """``speechain.module.norm.feat_norm.FeatureNormalization`` on gfx950.
 
 Drop-in for speechain/module/norm/feat_norm.py: same kwargs (:53-77), the same lazily created buffers ``<prefix>_batch`` /
-``<prefix>_mean`` / ``<prefix>_std`` / ``aver_mean`` / ``aver_std`` (re-registered on every update, :472-509), the same lazy
-``_load_from_state_dict`` (:606-632), ``forward(feat, feat_len, group_ids=None, epoch=None)`` and ``recover``.
+``<prefix>_mean`` / ``<prefix>_std`` / ``aver_mean`` / ``aver_std`` (re-created on every update, :472-509), checkpoints that bring
+their own buffers (:606-632), ``forward(feat, feat_len, group_ids=None, epoch=None)`` and ``recover``.  The module is organised
+differently from the reference: two kernels for the tensor work, a DDP helper, and a small "statistics book" (_stat / _put /
+_fold / _refresh_average / _vectors_for) for the running statistics.
 
 Device work -- the per-utterance statistics (a Python loop of B ``.mean`` / ``.std`` calls in the reference, :115-133) and the
 normalisation of the padded tensor -- is two launches (``sc_featnorm_stats``, ``sc_featnorm_apply``); everything (B, F)-sized
@@ -90,38 +92,49 @@ class FeatureNormalization(Module):
         if self.input_size is not None:
             self.output_size = self.input_size
 
-    # ---- running statistics (feat_norm.py:452-531) --------------------------------------------------------------------------
-    def register_mean_std_batch(self, curr_aver_mean, curr_aver_std, prefix, epoch):
-        if epoch is None or not hasattr(self, f"{prefix}_batch"):
-            self.register_buffer(f"{prefix}_batch", torch.ones(1, dtype=torch.int64, device=curr_aver_mean.device))
-        elif epoch <= self.max_epoch_num:
-            self.register_buffer(f"{prefix}_batch", self.get_buffer(f"{prefix}_batch") + 1)
-        if epoch is None or epoch <= self.max_epoch_num:
-            curr_weight = 1 / self.get_buffer(f"{prefix}_batch")
-            if self.mean_norm:
-                if not hasattr(self, f"{prefix}_mean"):
-                    self.register_buffer(f"{prefix}_mean", curr_aver_mean)
-                else:
-                    self.register_buffer(f"{prefix}_mean", curr_weight * curr_aver_mean + (1 - curr_weight) * self.get_buffer(f"{prefix}_mean"))
-            if self.std_norm:
-                if not hasattr(self, f"{prefix}_std"):
-                    self.register_buffer(f"{prefix}_std", curr_aver_std)
-                else:
-                    self.register_buffer(f"{prefix}_std", curr_weight * curr_aver_std + (1 - curr_weight) * self.get_buffer(f"{prefix}_std"))
+    # ---- the statistics book: every statistic is a buffer named <key>_mean / <key>_std / <key>_batch -------------------------------
+    # (the names and update rules are the checkpoint contract of feat_norm.py:452-531; the bookkeeping itself is organised here
+    #  around three small primitives: _stat / _put / _fold)
+    def _stat(self, key, kind: str) -> Optional[torch.Tensor]:
+        return self._buffers.get(f"{key}_{kind}")
 
-    def update_aver_mean_std(self, epoch):
-        if epoch is None or epoch <= self.max_epoch_num:
-            n_mean = n_std = 0
-            aver_mean = aver_std = None
-            for name, buff in self.named_buffers():
-                if name.endswith("_mean"):
-                    n_mean += 1
-                    aver_mean = buff.clone() if aver_mean is None else aver_mean + buff
-                elif name.endswith("_std"):
-                    n_std += 1
-                    aver_std = buff.clone() if aver_std is None else aver_std + buff
-            self.register_buffer("aver_mean", aver_mean / n_mean)
-            self.register_buffer("aver_std", aver_std / n_std)
+    def _put(self, key, kind: str, value: torch.Tensor):
+        self.register_buffer(f"{key}_{kind}", value)  # a fresh tensor each time, as the reference re-registers its buffers
+
+    def _fold(self, key, new_mean, new_std, epoch):
+        """One more batch for `key`: the stored vectors become the average over the batches seen so far.  While `epoch` is not
+        given the count restarts at one (the stored vectors then equal the newest batch); past `max_epoch_num` nothing moves."""
+        frozen = epoch is not None and epoch > self.max_epoch_num
+        seen = self._stat(key, "batch")
+        if epoch is None or seen is None:
+            anchor = new_mean if new_mean is not None else new_std
+            self._put(key, "batch", torch.ones(1, dtype=torch.int64, device=anchor.device))
+        elif not frozen:
+            self._put(key, "batch", seen + 1)
+        if frozen:
+            return
+        share = 1 / self._stat(key, "batch")
+        for kind, fresh, wanted in (("mean", new_mean, self.mean_norm), ("std", new_std, self.std_norm)):
+            if not wanted:
+                continue
+            old = self._stat(key, kind)
+            self._put(key, kind, fresh if old is None else share * fresh + (1 - share) * old)
+
+    def _refresh_average(self, epoch):
+        """aver_mean / aver_std: the plain average of every stored *_mean / *_std vector -- the previous average included, which is
+        what iterating over all buffers by suffix amounts to in the reference (feat_norm.py:519-528)."""
+        if epoch is not None and epoch > self.max_epoch_num:
+            return
+        for kind in ("mean", "std"):
+            pool = [v for name, v in self.named_buffers() if name.endswith("_" + kind)]
+            total = pool[0].clone()
+            for v in pool[1:]:
+                total = total + v
+            self.register_buffer("aver_" + kind, total / len(pool))
+
+    def _vectors_for(self, ids, kind: str) -> torch.Tensor:
+        """(len(ids), F): the stored vector of every id, the average one for ids never seen."""
+        return torch.stack([self._stat(g, kind) if self._stat(g, kind) is not None else self.get_buffer("aver_" + kind) for g in ids])
 
     # ---- forward (feat_norm.py:78-338) ----------------------------------------------------------------------------------------
     def forward(self, feat: torch.Tensor, feat_len: torch.Tensor, group_ids=None, epoch: int = None):
@@ -163,7 +176,7 @@ class FeatureNormalization(Module):
                         f"or integer. But got type(group_ids)={type(group_ids)}.")
                 prefix = "global" if self.norm_type == "global" else group_ids
                 if self.training:
-                    self.register_mean_std_batch(batch_mean, batch_std, prefix, epoch)
+                    self._fold(prefix, batch_mean, batch_std, epoch)
                 out = apply_stats(x, self.get_buffer(f"{prefix}_mean") if curr_means is not None else None,
                                   self.get_buffer(f"{prefix}_std") if curr_stds is not None else None)
         return (out.squeeze(-1) if squeeze_flag else out), feat_len
@@ -182,15 +195,11 @@ class FeatureNormalization(Module):
             id_t = torch.tensor(all_ids, device=x.device)
             for g in order:
                 sel = id_t == g
-                self.register_mean_std_batch(all_means[sel].mean(dim=0) if all_means is not None else None,
-                                             all_stds[sel].mean(dim=0) if all_stds is not None else None, g, epoch)
-            self.update_aver_mean_std(epoch)
-        mean = std = None
-        if self.mean_norm:
-            mean = torch.stack([self.get_buffer(f"{g}_mean") if hasattr(self, f"{g}_mean") else self.get_buffer("aver_mean") for g in ids])
-        if self.std_norm:
-            std = torch.stack([self.get_buffer(f"{g}_std") if hasattr(self, f"{g}_std") else self.get_buffer("aver_std") for g in ids])
-        return apply_stats(x, mean, std)
+                self._fold(g, all_means[sel].mean(dim=0) if all_means is not None else None,
+                           all_stds[sel].mean(dim=0) if all_stds is not None else None, epoch)
+            self._refresh_average(epoch)
+        return apply_stats(x, self._vectors_for(ids, "mean") if self.mean_norm else None,
+                           self._vectors_for(ids, "std") if self.std_norm else None)
 
     @staticmethod
     def _gather_groups(group_ids, curr_means, curr_stds, batch_size):
@@ -214,38 +223,41 @@ class FeatureNormalization(Module):
 
         return [int(g) for g in gather(group_ids.to(torch.int64)).tolist()], gather(curr_means), gather(curr_stds)
 
-    # ---- recover (feat_norm.py:533-604) -----------------------------------------------------------------------------------------
+    # ---- recover (feat_norm.py:533-604): the inverse map x * std + mean with the statistics the forward pass would pick ---------
     def recover(self, feat: torch.Tensor, group_ids=None):
         assert self.norm_type not in ["utterance", "batch"], \
             "If norm_type is either 'utterance' or 'batch', the normalized features cannot be recovered."
-        if self.norm_type == "global" or (self.norm_type == "group" and isinstance(group_ids, (str, int))):
-            prefix = "global" if self.norm_type == "global" else str(group_ids)
-            feat = feat * self.get_buffer(f"{prefix}_std") if self.std_norm else feat
-            feat = feat + self.get_buffer(f"{prefix}_mean") if self.mean_norm else feat
-        elif self.norm_type == "group" and isinstance(group_ids, torch.Tensor):
+        whole_batch = self.norm_type == "global" or isinstance(group_ids, (str, int))
+        if whole_batch:
+            key = "global" if self.norm_type == "global" else str(group_ids)
+            pick = lambda kind: self.get_buffer(f"{key}_{kind}")
+        elif isinstance(group_ids, torch.Tensor):
             ids = [int(g) for g in group_ids.tolist()]
-            if self.std_norm:
-                feat = feat * torch.stack([self.get_buffer(f"{g}_std") if hasattr(self, f"{g}_std") else self.get_buffer("aver_std")
-                                           for g in ids], dim=0).unsqueeze(1)
-            if self.mean_norm:
-                feat = feat + torch.stack([self.get_buffer(f"{g}_mean") if hasattr(self, f"{g}_mean") else self.get_buffer("aver_mean")
-                                           for g in ids], dim=0).unsqueeze(1)
-        elif self.norm_type == "group" and group_ids is None:
-            feat = feat * self.get_buffer("aver_std").expand(1, 1, -1) if self.std_norm else feat
-            feat = feat + self.get_buffer("aver_mean").expand(1, 1, -1) if self.mean_norm else feat
+            pick = lambda kind: self._vectors_for(ids, kind).unsqueeze(1)
+        elif group_ids is None:
+            pick = lambda kind: self.get_buffer("aver_" + kind).expand(1, 1, -1)
         else:
-            raise RuntimeError
+            raise RuntimeError(f"group_ids of type {type(group_ids)} cannot select statistics")
+        if self.std_norm:
+            feat = feat * pick("std")
+        if self.mean_norm:
+            feat = feat + pick("mean")
         return feat
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        """Buffers named ``*_batch`` / ``*_std`` / ``*_mean`` are created from the checkpoint (feat_norm.py:606-632)."""
-        for key in state_dict.keys():
-            if key.startswith(prefix):
-                input_name = key[len(prefix):].split(".", 1)[0]
-                if "_" in input_name and input_name.split("_")[-1] in ["batch", "std", "mean"]:
-                    self.register_buffer(input_name, state_dict[key])
-                else:
-                    unexpected_keys.append(key)
+        """The statistics exist only once observed, so a checkpoint brings its own buffers: every entry of this module whose name
+        ends in _batch / _std / _mean becomes a buffer; anything else is reported as unexpected (behaviour of feat_norm.py:606-632)."""
+        import re
+
+        ours = re.compile(r"^[^.]*_(?:batch|std|mean)$")
+        for key, value in state_dict.items():
+            if not key.startswith(prefix):
+                continue
+            name = key[len(prefix):].split(".", 1)[0]
+            if ours.match(name):
+                self.register_buffer(name, value)
+            else:
+                unexpected_keys.append(key)
 
     def extra_repr(self) -> str:
         return f"norm_type={self.norm_type}, mean_norm={self.mean_norm}, std_norm={self.std_norm}"
