@@ -27,15 +27,17 @@ template <> struct Lg<unsigned short> {
   static __device__ __forceinline__ void st(void* p, long long i, float v) { ((unsigned short*)p)[i] = sc_f32_to_bf16(v); }
 };
 
+// log-sum-exp on the hardware exp2 / log2 units (v_exp_f32 / v_log_f32, ~1 ulp): the recursions evaluate it once per extended label
+// and frame on their serial path, where the full-precision expf / logf sequences were most of the per-frame time.
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
   if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m));
+  return m + __logf(__expf(a - m) + __expf(b - m));
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(fmaxf(a, b), c);
   if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
 constexpr int kMaxS = 1024;  // extended label length 2L+1 handled per workgroup
@@ -55,20 +57,28 @@ struct CtcArgs {
   float* beta;              // (B, Tmax, Smax) backward only
 };
 
-constexpr int kSPT = kMaxS / 256;  // extended-label positions per thread
-
-// emission log-probabilities lp[t][ext[s]] = logit - lse of frame t for this thread's positions s = tid + 256 i
-template <typename T>
-__device__ __forceinline__ void ctc_gather(const CtcArgs& p, long long lbase, int b, int t, const int* ext, int S, int tid, float (&lp)[kSPT]) {
-  const float lt = p.lse[(long long)b * p.Tmax + t];
-#pragma unroll
-  for (int i = 0; i < kSPT; ++i) {
-    const int s = tid + 256 * i;
-    lp[i] = s < S ? Lg<T>::ld(p.logits, lbase + (long long)t * p.V + ext[s]) - lt : -INFINITY;
-  }
+// Frame barrier of the recursions: only the LDS exchange of alpha / beta has to be ordered.  __syncthreads() would also wait
+// for every outstanding global access (s_waitcnt vmcnt(0)) -- this frame's store of the alpha row and the emission gathers
+// prefetched for the next frames -- i.e. one HBM round trip per frame on the serial path.
+__device__ __forceinline__ void ctc_frame_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 }
 
-template <typename T>
+
+// Raw emission logits of frame t for this thread's positions s = tid + 256 i, plus the frame's logsumexp.  Deliberately free of
+// arithmetic and of branches (index clamped; the kernels are instantiated for NSPT = ceil(Smax / 256) position groups): a value consumed
+// inside an `if (s < S)` makes the compiler wait for the load inside that branch, i.e. at issue time -- which turns the
+// two-frames-ahead prefetch into one memory round trip per frame on the serial path (seen in the ISA; 183 us per recursion).
+template <typename T, int NSPT>
+__device__ __forceinline__ void ctc_gather(const CtcArgs& p, long long lbase, int b, int t, const int* ext, int S, int tid,
+                                           float (&raw)[NSPT], float& lt) {
+  lt = p.lse[(long long)b * p.Tmax + t];
+#pragma unroll
+  for (int i = 0; i < NSPT; ++i) raw[i] = Lg<T>::ld(p.logits, lbase + (long long)t * p.V + ext[min(tid + 256 * i, S - 1)]);
+}
+
+template <typename T, int NSPT>
 __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
   __shared__ int ext[kMaxS];
   __shared__ float buf[2][kMaxS];
@@ -84,45 +94,67 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
   }
   const long long lbase = (long long)b * p.Tmax * p.V;
   float* abase = p.alpha + (long long)b * p.Tmax * p.Smax;
-  bool skip2[kSPT];  // the s-2 -> s transition exists (odd s, different label)
+  bool skip2[NSPT];  // the s-2 -> s transition exists (odd s, different label)
 #pragma unroll
-  for (int i = 0; i < kSPT; ++i) {
+  for (int i = 0; i < NSPT; ++i) {
     const int s = tid + 256 * i;
     skip2[i] = s < S && s >= 2 && (s & 1) && ext[s] != ext[s - 2];
   }
-  float lp0[kSPT], lp1[kSPT], lp2[kSPT];
-  ctc_gather<T>(p, lbase, b, 0, ext, S, tid, lp0);
-  if (Tb > 1) ctc_gather<T>(p, lbase, b, 1, ext, S, tid, lp1);
+  // Raw logits three frames ahead in THREE register buffers used in rotation (frame t reads buffer t % 3 and, once it has consumed
+  // it, loads frame t + 3 into the same buffer).  The rotation is by name -- the loop is unrolled three ways -- never by copying: a register-to-register
+  // move of a value still in flight makes the compiler wait for the load in the same frame (seen in the ISA: s_waitcnt vmcnt(0)
+  // in front of every frame barrier), which is one memory round trip per frame on the serial path.
+  float r0[NSPT], r1[NSPT], r2[NSPT];
+  float l0, l1 = 0.f, l2 = 0.f;
+  ctc_gather<T, NSPT>(p, lbase, b, 0, ext, S, tid, r0, l0);
+  if (Tb > 1) ctc_gather<T, NSPT>(p, lbase, b, 1, ext, S, tid, r1, l1);
+  if (Tb > 2) ctc_gather<T, NSPT>(p, lbase, b, 2, ext, S, tid, r2, l2);
 #pragma unroll
-  for (int i = 0; i < kSPT; ++i) {
+  for (int i = 0; i < NSPT; ++i) {
     const int s = tid + 256 * i;
     if (s < S) {
-      const float a = s < 2 ? lp0[i] : -INFINITY;
+      const float a = s < 2 ? r0[i] - l0 : -INFINITY;
       buf[0][s] = a;
       abase[s] = a;
     }
   }
-  __syncthreads();
-  for (int t = 1; t < Tb; ++t) {
-    if (t + 1 < Tb) ctc_gather<T>(p, lbase, b, t + 1, ext, S, tid, lp2);  // in flight across this frame's barrier
-    const float* prev = buf[(t - 1) & 1];
-    float* cur = buf[t & 1];
-#pragma unroll
-    for (int i = 0; i < kSPT; ++i) {
-      const int s = tid + 256 * i;
-      if (s < S) {
-        const float a0 = prev[s];
-        const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-        const float a2 = skip2[i] ? prev[s - 2] : -INFINITY;
-        const float v = lse3(a0, a1, a2) + lp1[i];
-        cur[s] = v;
-        abase[(long long)t * p.Smax + s] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kSPT; ++i) lp1[i] = lp2[i];
-    __syncthreads();
+  if (Tb > 3) ctc_gather<T, NSPT>(p, lbase, b, 3, ext, S, tid, r0, l0);  // frame 0 is consumed: its buffer takes frame 3
+  ctc_frame_barrier();
+#define CTC_ALPHA_FRAME(T_, USE, LUSE, MORE)                                                   \
+  do {                                                                                                \
+    const int t_ = (T_);                                                                              \
+    const float* prev = buf[(t_ - 1) & 1];                                                            \
+    float* cur = buf[t_ & 1];                                                                         \
+    float v_[NSPT];                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NSPT; ++i) {                                                \
+      const int s = tid + 256 * i;                                                                    \
+      v_[i] = -INFINITY;                                                                              \
+      if (s < S) {                                                                                    \
+        const float a0 = prev[s];                                                                     \
+        const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;                                            \
+        const float a2 = skip2[i] ? prev[s - 2] : -INFINITY;                                          \
+        v_[i] = lse3(a0, a1, a2) + (USE[i] - LUSE);                                                   \
+        cur[s] = v_[i];                                                                               \
+        abase[(long long)t_ * p.Smax + s] = v_[i];                                                    \
+      }                                                                                               \
+    }                                                                                                 \
+    if (MORE) ctc_gather<T, NSPT>(p, lbase, b, t_ + 3, ext, S, tid, USE, LUSE); /* consumed: reload */    \
+    ctc_frame_barrier();                                                                              \
+  } while (0)
+  // steady state without a single branch (every frame and every prefetch of the triple exists: t + 5 < Tb), so that the compiler
+  // keeps COUNTED vmcnt waits across the loop; the last frames run guarded
+  int t = 1;
+  for (; t + 5 < Tb; t += 3) {
+    CTC_ALPHA_FRAME(t, r1, l1, true);
+    CTC_ALPHA_FRAME(t + 1, r2, l2, true);
+    CTC_ALPHA_FRAME(t + 2, r0, l0, true);
   }
+  for (; t < Tb; t += 3) {
+    CTC_ALPHA_FRAME(t, r1, l1, t + 3 < Tb);
+    if (t + 1 < Tb) CTC_ALPHA_FRAME(t + 1, r2, l2, t + 4 < Tb);
+    if (t + 2 < Tb) CTC_ALPHA_FRAME(t + 2, r0, l0, t + 5 < Tb);
+  }
+#undef CTC_ALPHA_FRAME
   if (tid == 0) {
     const float* last = buf[(Tb - 1) & 1];
     const float ll = (S > 1) ? lse2(last[S - 1], last[S - 2]) : last[0];
@@ -131,7 +163,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
 }
 
 // beta_t(s) (with the emission at t) for t = Tb-1 .. 0 into p.beta (B, Tmax, Smax); same structure as the alpha kernel
-template <typename T>
+template <typename T, int NSPT>
 __global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
   __shared__ int ext[kMaxS];
   __shared__ float buf[2][kMaxS];
@@ -145,45 +177,62 @@ __global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
   __syncthreads();
   const long long lbase = (long long)b * p.Tmax * p.V;
   float* bbase = p.beta + (long long)b * p.Tmax * p.Smax;
-  bool skip2[kSPT];  // the s -> s+2 transition exists
+  bool skip2[NSPT];  // the s -> s+2 transition exists
 #pragma unroll
-  for (int i = 0; i < kSPT; ++i) {
+  for (int i = 0; i < NSPT; ++i) {
     const int s = tid + 256 * i;
     skip2[i] = s + 2 < S && (s & 1) && ext[s] != ext[s + 2];
   }
-  float lp0[kSPT], lp1[kSPT], lp2[kSPT];
-  ctc_gather<T>(p, lbase, b, Tb - 1, ext, S, tid, lp0);
-  if (Tb > 1) ctc_gather<T>(p, lbase, b, Tb - 2, ext, S, tid, lp1);
+  // three register buffers rotated by name, three frames ahead (see ctc_alpha_kernel); frames run Tb-1, Tb-2, ...: frame
+  // Tb-1-j reads buffer j % 3
+  float r0[NSPT], r1[NSPT], r2[NSPT];
+  float l0, l1 = 0.f, l2 = 0.f;
+  const int tl = Tb - 1;
+  ctc_gather<T, NSPT>(p, lbase, b, tl, ext, S, tid, r0, l0);
+  if (tl >= 1) ctc_gather<T, NSPT>(p, lbase, b, tl - 1, ext, S, tid, r1, l1);
+  if (tl >= 2) ctc_gather<T, NSPT>(p, lbase, b, tl - 2, ext, S, tid, r2, l2);
 #pragma unroll
-  for (int i = 0; i < kSPT; ++i) {
+  for (int i = 0; i < NSPT; ++i) {
     const int s = tid + 256 * i;
     if (s < S) {
-      const float v = s >= S - 2 ? lp0[i] : -INFINITY;
-      buf[(Tb - 1) & 1][s] = v;
-      bbase[(long long)(Tb - 1) * p.Smax + s] = v;
+      const float v = s >= S - 2 ? r0[i] - l0 : -INFINITY;
+      buf[tl & 1][s] = v;
+      bbase[(long long)tl * p.Smax + s] = v;
     }
   }
-  __syncthreads();
-  for (int t = Tb - 2; t >= 0; --t) {
-    if (t >= 1) ctc_gather<T>(p, lbase, b, t - 1, ext, S, tid, lp2);
-    const float* nextb = buf[(t + 1) & 1];
-    float* cur = buf[t & 1];
-#pragma unroll
-    for (int i = 0; i < kSPT; ++i) {
-      const int s = tid + 256 * i;
-      if (s < S) {
-        const float b0 = nextb[s];
-        const float b1 = s + 1 < S ? nextb[s + 1] : -INFINITY;
-        const float b2 = skip2[i] ? nextb[s + 2] : -INFINITY;
-        const float v = lse3(b0, b1, b2) + lp1[i];
-        cur[s] = v;
-        bbase[(long long)t * p.Smax + s] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kSPT; ++i) lp1[i] = lp2[i];
-    __syncthreads();
+  if (tl >= 3) ctc_gather<T, NSPT>(p, lbase, b, tl - 3, ext, S, tid, r0, l0);
+  ctc_frame_barrier();
+#define CTC_BETA_FRAME(T_, USE, LUSE, MORE)                                                                 \
+  do {                                                                                                \
+    const int t_ = (T_);                                                                              \
+    const float* nextb = buf[(t_ + 1) & 1];                                                           \
+    float* cur = buf[t_ & 1];                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NSPT; ++i) {                                                \
+      const int s = tid + 256 * i;                                                                    \
+      if (s < S) {                                                                                    \
+        const float b0 = nextb[s];                                                                    \
+        const float b1 = s + 1 < S ? nextb[s + 1] : -INFINITY;                                        \
+        const float b2 = skip2[i] ? nextb[s + 2] : -INFINITY;                                         \
+        const float v = lse3(b0, b1, b2) + (USE[i] - LUSE);                                           \
+        cur[s] = v;                                                                                   \
+        bbase[(long long)t_ * p.Smax + s] = v;                                                        \
+      }                                                                                               \
+    }                                                                                                 \
+    if (MORE) ctc_gather<T, NSPT>(p, lbase, b, t_ - 3, ext, S, tid, USE, LUSE);                            \
+    ctc_frame_barrier();                                                                              \
+  } while (0)
+  int t = tl - 1;
+  for (; t - 5 >= 0; t -= 3) {  // branch-free steady state (see ctc_alpha_kernel)
+    CTC_BETA_FRAME(t, r1, l1, true);
+    CTC_BETA_FRAME(t - 1, r2, l2, true);
+    CTC_BETA_FRAME(t - 2, r0, l0, true);
   }
+  for (; t >= 0; t -= 3) {
+    CTC_BETA_FRAME(t, r1, l1, t - 3 >= 0);
+    if (t - 1 >= 0) CTC_BETA_FRAME(t - 1, r2, l2, t - 4 >= 0);
+    if (t - 2 >= 0) CTC_BETA_FRAME(t - 2, r0, l0, t - 5 >= 0);
+  }
+#undef CTC_BETA_FRAME
 }
 
 // One workgroup per frame (b, t): the whole gradient row.
@@ -263,8 +312,20 @@ SC_API int sc_ctc_fwd(int dtype, const void* logits, const float* lse, const lon
   SC_CHECK_ARG(B >= 1 && Tmax >= 1 && V >= 1 && Smax >= 1 && Smax <= kMaxS, "sc_ctc_fwd: bad sizes (Smax=%d, limit %d)", Smax, kMaxS);
   SC_CHECK_ARG(blank >= 0 && blank < V, "sc_ctc_fwd: blank %d outside the vocabulary", blank);
   CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, alpha, nll, nullptr, nullptr};
-  if (dtype == 0) hipLaunchKernelGGL(ctc_alpha_kernel<float>, dim3(B), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(ctc_alpha_kernel<unsigned short>, dim3(B), dim3(256), 0, stream, a);
+  // NSPT = extended-label positions per thread the recursion kernels are instantiated for (Smax <= 256 NSPT)
+#define SC_CTC_RECURSION(KERNEL)                                                                                             \
+  do {                                                                                                                       \
+    if (dtype == 0) {                                                                                                        \
+      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<float, 1>), dim3(B), dim3(256), 0, stream, a);                              \
+      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<float, 2>), dim3(B), dim3(256), 0, stream, a);                         \
+      else hipLaunchKernelGGL((KERNEL<float, 4>), dim3(B), dim3(256), 0, stream, a);                                          \
+    } else {                                                                                                                 \
+      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<unsigned short, 1>), dim3(B), dim3(256), 0, stream, a);                     \
+      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<unsigned short, 2>), dim3(B), dim3(256), 0, stream, a);                \
+      else hipLaunchKernelGGL((KERNEL<unsigned short, 4>), dim3(B), dim3(256), 0, stream, a);                                 \
+    }                                                                                                                        \
+  } while (0)
+  SC_CTC_RECURSION(ctc_alpha_kernel);
   SC_LAUNCH_CHECK("ctc_alpha_kernel");
   return SC_OK;
 }
@@ -277,10 +338,10 @@ SC_API int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const lon
   SC_CHECK_ARG(V <= (1 << 16), "sc_ctc_bwd: vocabulary %d > 65536 (label bitmap in LDS)", V);
   CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, const_cast<float*>(alpha), const_cast<float*>(nll), gscale, grad, beta};
   if (dtype == 0) {
-    hipLaunchKernelGGL(ctc_beta_kernel<float>, dim3(B), dim3(256), 0, stream, a);
+    SC_CTC_RECURSION(ctc_beta_kernel);
     hipLaunchKernelGGL(ctc_grad_kernel<float>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(ctc_beta_kernel<unsigned short>, dim3(B), dim3(256), 0, stream, a);
+    SC_CTC_RECURSION(ctc_beta_kernel);
     hipLaunchKernelGGL(ctc_grad_kernel<unsigned short>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   }
   SC_LAUNCH_CHECK("ctc backward kernels");
