@@ -115,7 +115,7 @@ class ASRTrainStepWorkload:
 
     dtype = "bf16"
 
-    def __init__(self, device, seed, world, prenet_dims=(64, 64)):
+    def __init__(self, device, seed, world, prenet_dims=(64, 64), distributed=False):
         self.prenet_dims = tuple(prenet_dims)
         self.name = ("ASR transformer-base train step (12enc/6dec d512 h8 ffn2048 V5000, bf16) from 32x10s@16kHz waveforms: frontend + "
                      f"global mean/std normalisation + specaug + conv2d-prenet{list(self.prenet_dims)} + encoder + decoder + "
@@ -132,7 +132,10 @@ class ASRTrainStepWorkload:
         Fn.set_attention_probs(False)  # the train step never reads the attention maps: fused attention, no score tensors in HBM
         torch.manual_seed(0)  # identical initial weights on every rank
         self.fe = Speech2MelSpec(**ASR_FRONTEND).to(device)
-        self.norm = FeatureNormalization(input_size=80).to(device).train()  # the recipes' `normalize: True` (global mean / std)
+        # the recipes' `normalize: True` (global mean / std); under DDP its statistics are gathered over the ranks every step, as the
+        # reference does (module/encoder/asr.py:55-57 passes `distributed`; feat_norm.py:236-265) -- they are buffers, so nothing else
+        # would keep the ranks' normalisation identical
+        self.norm = FeatureNormalization(input_size=80, distributed=distributed).to(device).train()
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
         self.prenet = Conv2dSubsample(80, self.prenet_dims, 512).to(device).train()
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
@@ -394,7 +397,7 @@ def main():
 
     torch.manual_seed(1234 + rank)
     prenet_dims = tuple(int(c) for c in args.prenet_dims.split(","))
-    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world, prenet_dims)
+    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world, prenet_dims, distributed=dist is not None)
     for _ in range(args.warmup):
         wl.step(False)
 
@@ -446,7 +449,8 @@ def main():
                        "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
                                     f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
                                     "buckets, issued between the backward hipGraph and the optimizer hipGraph (not overlapped with "
-                                    "backward in this graph-captured step)")},
+                                    "backward in this graph-captured step); plus the two (80,)-vector all-gathers of the feature "
+                                    "normalisation statistics in the eager part of the step, as in the reference")},
             "roofline": roof,
         }
         if args.workload == "asr_train_step":
