@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x, const
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, const void* x, const float* mean, const float* rstd,
                                                             const float* gamma, void* dx, float* part, long long R, int D,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, const void* dres) {
   extern __shared__ float red[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float dg[NI], db[NI];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* dy, cons
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = lane + 64 * i;
-      if (k < D) Row<T>::st(dx, base + k, rs * (g[i] - s1 - xh[i] * s2));
+      if (k < D) Row<T>::st(dx, base + k, rs * (g[i] - s1 - xh[i] * s2) + (dres ? Row<T>::ld(dres, base + k) : 0.f));
     }
   }
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const unsigned s
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned short* dy, const unsigned short* x, const float* mean,
                                                                 const float* rstd, const float* gamma, unsigned short* dx, float* part,
-                                                                long long R, int D, int rows_per_block) {
+                                                                long long R, int D, int rows_per_block, const unsigned short* dres) {
   extern __shared__ float red[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float gm[NV][8], dg[NV][8], db[NV][8];
@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
     for (int c = 0; c < NV; ++c) {
       const int k = 8 * (lane + 64 * c);
       if (k < D) {
-        float o[8];
+        float o[8], rv[8];
+        if (dres) ln_unpack8(*reinterpret_cast<const uint4*>(dres + base + k), rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2);
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2) + (dres ? rv[e] : 0.f);
         *reinterpret_cast<uint4*>(dx + base + k) = ln_pack8(o);
       }
     }
@@ -541,8 +542,8 @@ SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
 }
 
 SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                            void* dx, float* dgamma, float* dbeta, long long R, int D, void* workspace, long long ws_bytes,
-                            hipStream_t stream) {
+                            void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
+                            long long ws_bytes, hipStream_t stream) {
   SC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "sc_layernorm_bwd: null pointer");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
   SC_CHECK_ARG(ws_bytes >= sc_layernorm_bwd_workspace(R, D), "sc_layernorm_bwd: workspace too small");
@@ -552,16 +553,16 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   blocks = (R + rpb - 1) / rpb;
   const size_t smem = (size_t)8 * D * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_layernorm_bwd: D too large for the LDS reduction");
-  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) % 16 == 0);
+  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
   if (vec) {
     const dim3 grid((unsigned)blocks);
     const unsigned short *dy16 = (const unsigned short*)dy, *x16 = (const unsigned short*)x;
-    if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
-    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
-    else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb);
+    if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
+    else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
   } else {
     SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
-                  (float*)workspace, R, D, rpb);
+                  (float*)workspace, R, D, rpb, dres);
   }
   SC_LAUNCH_CHECK("layernorm_bwd_kernel");
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(1024), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);

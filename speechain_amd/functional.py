@@ -578,8 +578,13 @@ def ffn(x, w1, b1, w2, b2, activation: str, p_hidden: float = 0.0, p_res: float 
 # ---------------------------------------------------------------------------------------------------------------------
 
 class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last dim.  With `with_residual` the input is also returned unchanged as a second output for the residual
+    connection of a pre-LN block to use: the block input then reaches autograd through this function only, backward receives both of
+    its gradients (through the norm and through the residual path) and the kernel adds them before the store -- instead of a
+    separate elementwise sum launched by autograd for every sublayer."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, with_residual):
         require_gpu(x, "layer norm")
         D = x.size(-1)
         x2 = x.reshape(-1, D)
@@ -594,27 +599,42 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, gamma)
         ctx.beta_param = beta
         ctx.xshape = x.shape
+        ctx.with_residual = with_residual
+        if with_residual:
+            return y.reshape(x.shape), x.view_as(x)
         return y.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x2, mean, rstd, gamma = ctx.saved_tensors
         R, D = x2.shape
+        if dy is None:  # the normalised output was not used: only the residual path carries a gradient
+            return dres, None, None, None, None
         dy2 = dy.reshape(R, D)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        dr2 = None
+        if dres is not None:
+            dr2 = dres.reshape(R, D).to(dy2.dtype)
+            if not dr2.is_contiguous():
+                dr2 = dr2.contiguous()
         dx = torch.empty_like(x2)
         sg, sb = GradSinks.take([gamma]), GradSinks.take([ctx.beta_param])
         dg = sg if sg is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         db = sb if sb is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         ws = torch.empty(lib.value("sc_layernorm_bwd_workspace", R, D), dtype=torch.uint8, device=x2.device)
         lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
-                 _p(ws), ws.numel(), stream())
-        return dx.reshape(ctx.xshape), dg, db, None
+                 _p(dr2), _p(ws), ws.numel(), stream())
+        return dx.reshape(ctx.xshape), dg, db, None, None
 
 
 def layer_norm(x, gamma, beta, eps: float):
-    return _LayerNorm.apply(x, gamma, beta, eps)
+    return _LayerNorm.apply(x, gamma, beta, eps, False)
+
+
+def layer_norm_with_residual(x, gamma, beta, eps: float):
+    """(LayerNorm(x), x): use the second output for the residual connection (see _LayerNorm)."""
+    return _LayerNorm.apply(x, gamma, beta, eps, True)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ from torch import nn
 from speechain_amd import functional as Fn
 from speechain_amd.module.abs import Module
 from speechain_amd.module.transformer.attention import MultiHeadedAttention
-from speechain_amd.module.transformer.encoder import _ln
+from speechain_amd.module.transformer.encoder import _ln, _ln_res
 from speechain_amd.module.transformer.feed_forward import PositionwiseFeedForward
 from speechain_amd.module.transformer.pos_enc import PositionalEncoding
 
@@ -37,15 +37,16 @@ class TransformerDecoderLayer(Module):
         tgt, src = Fn.to_compute(tgt), Fn.to_compute(src)
         p = self.dropout.p if self.training else 0.0
         first = self.layernorm_first
-        tgt_norm = _ln(self.self_att_ln, tgt) if first else tgt
+        # (pre-LN: _ln_res returns the sublayer input again for the residual connection, see encoder.py)
+        tgt_norm, tgt = _ln_res(self.self_att_ln, tgt) if first else (tgt, tgt)
         x, self_attmat = self.self_att(tgt_norm, tgt_norm, tgt_norm, mask=tgt_mask, _residual=tgt, _res_drop=p, _causal=_causal)
         if not first:
             x = _ln(self.self_att_ln, x)
-        x_norm = _ln(self.encdec_att_ln, x) if first else x
+        x_norm, x = _ln_res(self.encdec_att_ln, x) if first else (x, x)
         y, encdec_attmat = self.encdec_att(src, src, x_norm, mask=src_mask, _residual=x, _res_drop=p)
         if not first:
             y = _ln(self.encdec_att_ln, y)
-        y_norm = _ln(self.fdfwd_ln, y) if first else y
+        y_norm, y = _ln_res(self.fdfwd_ln, y) if first else (y, y)
         out = self.feed_forward(y_norm, _residual=y, _res_drop=p)
         if not first:
             out = _ln(self.fdfwd_ln, out)

@@ -25,6 +25,11 @@ def _ln(mod: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return Fn.layer_norm(x, mod.weight, mod.bias, mod.eps)
 
 
+def _ln_res(mod: nn.LayerNorm, x: torch.Tensor):
+    """(LayerNorm(x), x for the residual connection): both gradients of x are summed inside the LayerNorm backward kernel."""
+    return Fn.layer_norm_with_residual(x, mod.weight, mod.bias, mod.eps)
+
+
 class TransformerEncoderLayer(Module):
     def module_init(self, d_model: int = 512, num_heads: int = 8, scale_dp_by_head: bool = False, att_dropout: float = 0.1,
                     fdfwd_dim: int = 2048, fdfwd_type: str = "linear", fdfwd_activation: str = "ReLU",
@@ -42,11 +47,13 @@ class TransformerEncoderLayer(Module):
     def forward(self, src: torch.Tensor, mask: torch.Tensor, *, _causal: bool = False):
         src = Fn.to_compute(src)
         p = self.dropout.p if self.training else 0.0
-        src_norm = _ln(self.att_layernorm, src) if self.layernorm_first else src
+        # pre-LN: the sublayer input feeds the norm AND the residual connection; _ln_res hands it back so that both of its
+        # gradients meet inside the LayerNorm backward kernel
+        src_norm, src = _ln_res(self.att_layernorm, src) if self.layernorm_first else (src, src)
         att_output, attmat = self.multihead_att(src_norm, src_norm, src_norm, mask, _residual=src, _res_drop=p, _causal=_causal)
         if not self.layernorm_first:
             att_output = _ln(self.att_layernorm, att_output)
-        att_norm = _ln(self.fdfwd_layernorm, att_output) if self.layernorm_first else att_output
+        att_norm, att_output = _ln_res(self.fdfwd_layernorm, att_output) if self.layernorm_first else (att_output, att_output)
         out = self.feed_forward(att_norm, _residual=att_output, _res_drop=p)
         if not self.layernorm_first:
             out = _ln(self.fdfwd_layernorm, out)
