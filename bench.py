@@ -172,6 +172,10 @@ class ASRTrainStepWorkload:
         x, xlen = self.prenet(self.feat, self.flen)
         out = self.model(x, xlen, self.text, self.text_len)
         out["loss"].backward()
+        # gradients that stock torch ops produced (conv prenet, token embedding) are copied into their bucket slots HERE, inside the
+        # region that is captured: the clip below works on the flat buckets and the all-reduce ships them, so after a replay the
+        # slots must hold this step's values (tests/test_bench_step_gpu.py)
+        self.reducer.settle()
         return out["loss"].detach()
 
     def _tail(self):

@@ -146,6 +146,13 @@ class GradBucketReducer:
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.pg)
 
+    def settle(self):
+        """Public form of the step below for callers that capture backward into a hipGraph: called INSIDE the captured region,
+        right after ``backward()``, the copies become part of the graph (a replay writes torch-produced gradients into static
+        tensors of the capture, not into the slots) and every ``param.grad`` is a slot view by the time the optimizer is captured."""
+        if self.use_sinks:
+            self._settle()
+
     def _settle(self):
         """Makes every ``param.grad`` the view of its bucket slot again: gradients produced outside the sink-aware kernels
         (torch ops, second contributions, cloned tensors) are copied in; parameters without a gradient get zeros."""
