@@ -84,6 +84,58 @@ int sc_featnorm_apply(const float* feat, float* out, long long stride_b, long lo
                       long long out_stride_t, int B, int T, int F, const float* mean, long long mean_stride_b, const float* std,
                       long long std_stride_b, hipStream_t stream);
 
+/* ---- Conv2d prenet (speechain/module/prenet/conv2d.py:168-205 construction, :227-280 forward) ---------------------------------
+ * [Conv2d(kernel KH x KW, stride SH x SW, zero padding PH x PW) -> BatchNorm2d -> activation] blocks on a (B, T, F) feature image.
+ * Every intermediate is channels-last: (B, To, Fo, C), i.e. a (B*To*Fo, C) matrix in `dtype` (0 = f32, 1 = bf16).  Geometry
+ * arguments must satisfy To = (Ti + 2 PH - KH) / SH + 1 (same for Fo).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ *
+ * First block (one input channel, KK = KH*KW <= 15 taps; replaces nn.Conv2d(1, C) + nn.BatchNorm2d + activation at conv2d.py:171-190):
+ *   sc_conv1_moments  moments[KK*KK + KK] (float64) = sum over all output positions of patch patch^T, then of patch; x is the (B, Ti, Fi)
+ *                     f32 image with strides (stride_b, stride_t, 1).
+ *   sc_conv1_bn_coeffs  per channel, from the moments and w (C, KK): batch mean / biased variance of z = w.patch, scale = gamma*rstd,
+ *                     shift = beta - mean*scale, saved mean / rstd; running_mean / running_var (nullable) move by `momentum` with the
+ *                     unbiased variance, as torch.nn.BatchNorm2d in training mode.
+ *   sc_conv1_apply    y[b][to][fo][c] = act(scale[c] * (w[c] . patch) + shift[c])   (no BatchNorm: scale = 1, shift = conv bias).
+ *   sc_conv1_bwd      from dy (same layout as y): dw (C, KK), dgamma (C), dbeta (C; the bias gradient when mean == rstd == null).
+ *                     batch_stats = 1: gradients flow through the batch statistics (training mode), needs `moments`; 0: fixed statistics. */
+long long sc_conv1_moments_workspace(int B, int To, int KH, int KW);
+int sc_conv1_moments(const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
+                     int SH, int SW, int PH, int PW, double* moments, void* workspace, long long ws_bytes, hipStream_t stream);
+int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                       float* rstd, hipStream_t stream);
+int sc_conv1_apply(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH,
+                   int KW, int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act,
+                   float slope, void* y, hipStream_t stream);
+long long sc_conv1_bwd_workspace(int B, int To, int C, int KK);
+int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
+                 int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act, float slope,
+                 const void* dy, const double* moments, const float* gamma, const float* mean, const float* rstd, int batch_stats,
+                 float* dw, float* dgamma, float* dbeta, void* workspace, long long ws_bytes, hipStream_t stream);
+
+/* Blocks with C input channels (nn.Conv2d(C, C_out) at conv2d.py:171-180 as im2col + sc_gemm; its autograd as sc_gemm_splitk / sc_gemm +
+ * sc_col2im):  col[(b, to, fo)][(kh, kw, c)] = a[b][to*SH - PH + kh][fo*SW - PW + kw][c] (0 outside the image);
+ * sc_col2im is its adjoint, da[b][t][f][c] = sum of the dcol entries that read a[b][t][f][c] (a gather: deterministic). */
+int sc_im2col(int dtype, const void* a, int B, int Ti, int Fi, int C, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW,
+              void* col, hipStream_t stream);
+int sc_col2im(int dtype, const void* dcol, int B, int Ti, int Fi, int C, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW,
+              void* da, hipStream_t stream);
+
+/* nn.BatchNorm2d (+ activation) on a channels-last tensor = per-column statistics of an (M, C) matrix z (conv2d.py:184-190).
+ *   sc_bn_stats    batch mean / biased variance per column -> scale, shift, mean, rstd; running statistics updated as above.
+ *   sc_bn_act_fwd  y = act(scale[c] * z + shift[c])                (eval mode / no BatchNorm: the caller supplies scale and shift).
+ *   sc_bn_act_bwd  dz, dgamma (nullable), dbeta (nullable) from dy; batch_stats as in sc_conv1_bwd; mean == rstd == null: no BatchNorm
+ *                  (dz = scale * dy * act').  Workspace: sc_bn_workspace(M, C) bytes (+ 12*C for sc_bn_act_bwd). */
+long long sc_bn_workspace(long long M, int C);
+int sc_bn_stats(int dtype, const void* z, long long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, void* workspace,
+                long long ws_bytes, hipStream_t stream);
+int sc_bn_act_fwd(int dtype, const void* z, long long M, int C, const float* scale, const float* shift, int act, float slope, void* y,
+                  hipStream_t stream);
+int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, const float* mean,
+                  const float* rstd, int batch_stats, int act, float slope, void* dz, float* dgamma, float* dbeta, void* workspace,
+                  long long ws_bytes, hipStream_t stream);
+
 /* ---- SpecAugment -----------------------------------------------------------------------------------------
  * Replaces SpecAugment.forward after its random draws (speechain/module/augment/specaug.py:111-124 time warp,
  * :160-199 mask construction, :202-204 masked_fill).  in/out (B, T, F) f32.  warp_center < 0 disables the warp;

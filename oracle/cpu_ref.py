@@ -646,3 +646,81 @@ class FeatureNormalization:
         prefix = "global" if self.norm_type == "global" else str(group_ids)
         feat = feat * self.buffers[f"{prefix}_std"] if self.std_norm else feat
         return feat + self.buffers[f"{prefix}_mean"] if self.mean_norm else feat
+
+
+# ---- Conv2d prenet (row f2) ---------------------------------------------------------------------------------------------
+def conv2d_prenet_layout(conv_dims, conv_batchnorm: bool, conv_activation: Optional[str], conv_dropout, lnr_dims,
+                         zero_centered: bool = False) -> List[Dict[str, Optional[int]]]:
+    """Positions of each block's members inside the reference's ``nn.Sequential`` ``conv`` (conv2d.py:168-205): Conv2d, then
+    BatchNorm2d if ``conv_batchnorm``, then the activation unless (last block, no linear part, zero_centered and a ReLU-series
+    activation) (:186-190), then Dropout if ``conv_dropout``.  Parameter names follow: ``conv.{pos}.weight`` ..."""
+    out, pos = [], 0
+    for i in range(len(conv_dims)):
+        blk = dict(conv=pos, bn=None, act=False)
+        pos += 1
+        if conv_batchnorm:
+            blk["bn"] = pos
+            pos += 1
+        if conv_activation is not None:
+            if not (i == len(conv_dims) - 1 and lnr_dims is None) or not (zero_centered and "ReLU" in conv_activation):
+                blk["act"] = True
+                pos += 1
+        if conv_dropout is not None:
+            pos += 1
+        out.append(blk)
+    return out
+
+
+def conv2d_prenet(feat: Tensor, feat_len: Tensor, P: Dict[str, Tensor], prefix: str = "", *, conv_dims=(64, 64), conv_kernel=3,
+                  conv_stride=2, conv_padding=0, conv_batchnorm: bool = False, conv_activation: Optional[str] = "ReLU",
+                  lnr_dims=512, lnr_activation: Optional[str] = None, zero_centered: bool = False, training: bool = True,
+                  momentum: float = 0.1, bn_eps: float = 1e-5):
+    """Conv2dPrenet.forward (conv2d.py:227-280) + LinearPrenet.forward (linear.py:112-128), dropout off.
+    (B, T, F) -> unsqueeze(1) -> [Conv2d(k, s, p; bias iff no batchnorm) -> BatchNorm2d -> activation] x len(conv_dims) ->
+    (B, C, T', F') -> transpose(1, 2).view(B, T', C * F') (channel-major flattening, :251) -> Linear blocks.
+    Lengths: floor((len - k) / s) + 1 per block (:254-263; the padding is not counted there, as in the reference).
+    BatchNorm2d in training mode normalises with the biased batch variance and returns the updated running statistics
+    (momentum 0.1, unbiased variance) as ``stats[f'conv.{pos}.running_mean']`` ...; in eval mode it uses the running ones.
+    Inputs narrower than the receptive field are zero-padded first (:236-247).  Returns (out, out_len, stats)."""
+    conv_dims = [conv_dims] if isinstance(conv_dims, int) else list(conv_dims)
+    pair = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v, v)
+    kernel, stride, padding = pair(conv_kernel), pair(conv_stride), pair(conv_padding)
+    min_h = min_w = 1
+    for _ in conv_dims:  # (:141-152: both use index [0] of kernel / stride / padding)
+        min_h = (min_h - 1) * stride[0] + kernel[0] - 2 * padding[0]
+        min_w = (min_w - 1) * stride[0] + kernel[0] - 2 * padding[0]
+    if feat.size(1) < min_h:
+        d = min_h - feat.size(1)
+        feat = F.pad(feat, (0, 0, int(d / 2), d - int(d / 2)))
+        feat_len = feat_len + d
+    if feat.size(2) < min_w:
+        d = min_w - feat.size(2)
+        feat = F.pad(feat, (int(d / 2), d - int(d / 2)))
+    stats = {}
+    x = feat.unsqueeze(1)
+    for blk in conv2d_prenet_layout(conv_dims, conv_batchnorm, conv_activation, None, lnr_dims, zero_centered):
+        name = f"{prefix}conv.{blk['conv']}."
+        x = F.conv2d(x, P[name + "weight"], P.get(name + "bias"), stride=stride, padding=padding)
+        if blk["bn"] is not None:
+            bn = f"{prefix}conv.{blk['bn']}."
+            rm, rv = P[bn + "running_mean"].detach().clone(), P[bn + "running_var"].detach().clone()
+            x = F.batch_norm(x, rm, rv, P[bn + "weight"], P[bn + "bias"], training, momentum, bn_eps)
+            stats[bn + "running_mean"], stats[bn + "running_var"] = rm, rv
+        if blk["act"]:
+            x = _activation(conv_activation)(x)
+    B, C, T, Fd = x.shape
+    x = x.transpose(1, 2).contiguous().view(B, T, C * Fd)
+    for _ in conv_dims:
+        feat_len = torch.div(feat_len - kernel[0], stride[0], rounding_mode="floor") + 1
+    if int(feat_len.max()) != x.size(1):  # (:266-271) e.g. any conv_padding > 0 with stride 2, or a batch that is not tightly padded
+        raise RuntimeError("There is a bug in the Conv2dPrenet.The calculation of the feature lengths has something wrong.")
+    if lnr_dims is not None:
+        dims = [lnr_dims] if isinstance(lnr_dims, int) else list(lnr_dims)
+        pos = 0
+        for i in range(len(dims)):
+            x = F.linear(x, P[f"{prefix}linear.linear.{pos}.weight"], P[f"{prefix}linear.linear.{pos}.bias"])
+            pos += 1
+            if lnr_activation is not None and (i != len(dims) - 1 or not (zero_centered and "ReLU" in lnr_activation)):
+                x = _activation(lnr_activation)(x)
+                pos += 1
+    return x, feat_len, stats

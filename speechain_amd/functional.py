@@ -942,3 +942,214 @@ class _CTC(torch.autograd.Function):
 
 def ctc_nll(logits, in_len, tgt, tgt_len, blank: int = 0, zero_infinity: bool = True):
     return _CTC.apply(logits, in_len, tgt, tgt_len, int(blank), bool(zero_infinity))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Conv2d prenet blocks (csrc/prenet.hip): channels-last (B, T', F', C) images in the compute dtype
+# ---------------------------------------------------------------------------------------------------------------------
+PACT = {None: 0, "ReLU": 1, "LeakyReLU": 2}
+
+
+def conv_out_size(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+def _bn_eval_coeffs(gamma, beta, rm, rv, eps):
+    rstd = torch.rsqrt(rv.detach() + eps)
+    scale = gamma.detach() * rstd
+    return scale, beta.detach() - rm.detach() * scale, rm.detach().clone(), rstd
+
+
+def _sink_or_new(params, shape, device):
+    sink = GradSinks.take(params)
+    return sink.view(shape) if sink is not None else torch.empty(shape, dtype=torch.float32, device=device)
+
+
+class _ConvFirst(torch.autograd.Function):
+    """Conv2d(1, C, kernel, stride, padding) [+ BatchNorm2d] [+ activation] on a (B, T, F) float32 image -> (B, To, Fo, C).
+    Training-mode BatchNorm takes its statistics from the patch moments (no pre-normalisation tensor exists); the running
+    statistics are updated in place, as torch does."""
+
+    @staticmethod
+    def forward(ctx, feat, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps, dtype):
+        require_gpu(feat, "the Conv2d prenet")
+        (kh, kw), (sh, sw), (ph, pw) = geom
+        x = feat.detach()
+        if x.dtype != torch.float32 or x.stride(2) != 1:
+            x = x.float().contiguous()
+        B, Ti, Fi = x.shape
+        To, Fo = conv_out_size(Ti, kh, sh, ph), conv_out_size(Fi, kw, sw, pw)
+        C, KK = w.size(0), kh * kw
+        dev = x.device
+        w2 = w.detach().reshape(C, KK).contiguous()
+        g6 = (B, Ti, Fi, To, Fo, kh, kw, sh, sw, ph, pw)
+        moments = mean = rstd = None
+        bn = gamma is not None
+        if bn and training:
+            ws = torch.empty(lib.value("sc_conv1_moments_workspace", B, To, kh, kw), dtype=torch.uint8, device=dev)
+            moments = torch.empty(KK * KK + KK, dtype=torch.float64, device=dev)
+            lib.call("sc_conv1_moments", _p(x), x.stride(0), x.stride(1), *g6, _p(moments), _p(ws), ws.numel(), stream())
+            scale, shift, mean, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+            lib.call("sc_conv1_bn_coeffs", _p(moments), _p(w2), C, KK, B * To * Fo, _p(gamma.detach()), _p(beta.detach()), float(eps),
+                     float(momentum), _p(rm), _p(rv), _p(scale), _p(shift), _p(mean), _p(rstd), stream())
+        elif bn:
+            scale, shift, mean, rstd = _bn_eval_coeffs(gamma, beta, rm, rv, eps)
+        else:
+            scale = torch.ones(C, dtype=torch.float32, device=dev)
+            shift = bias.detach().float() if bias is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        y = torch.empty(B, To, Fo, C, dtype=dtype, device=dev)
+        lib.call("sc_conv1_apply", dcode(y), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope), _p(y),
+                 stream())
+        ctx.save_for_backward(x, w, scale, shift, moments, gamma, mean, rstd)
+        ctx.params = (w, bias, gamma, beta)
+        ctx.meta = (g6, act, slope, bn, bn and training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("speechain_amd Conv2d prenet: no gradient w.r.t. the input features (the frontend in front of it "
+                                      "has no trainable parameter, module/encoder/asr.py:103-131)")
+        x, w, scale, shift, moments, gamma, mean, rstd = ctx.saved_tensors
+        g6, act, slope, bn, batch_stats = ctx.meta
+        pw_, pb, pg, pbe = ctx.params
+        B, To, kh, kw = g6[0], g6[3], g6[5], g6[6]
+        C, KK = w.size(0), kh * kw
+        dev = x.device
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        w2 = w.detach().reshape(C, KK).contiguous()
+        dw = _sink_or_new([pw_], (C, KK), dev)
+        dgamma = _sink_or_new([pg], (C,), dev) if bn else None
+        dbeta = _sink_or_new([pbe], (C,), dev) if bn else (_sink_or_new([pb], (C,), dev) if pb is not None else None)
+        ws = torch.empty(lib.value("sc_conv1_bwd_workspace", B, To, C, KK), dtype=torch.uint8, device=dev)
+        lib.call("sc_conv1_bwd", dcode(dy), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope), _p(dy),
+                 _p(moments), _p(gamma.detach()) if bn else None, _p(mean), _p(rstd), 1 if batch_stats else 0, _p(dw), _p(dgamma), _p(dbeta),
+                 _p(ws), ws.numel(), stream())
+        return (None, dw.view_as(w), None if bn else dbeta, dgamma, dbeta if bn else None) + (None,) * 9
+
+
+class _ConvNext(torch.autograd.Function):
+    """Conv2d(Cin, Cout, kernel, stride, padding) [+ BatchNorm2d] [+ activation] on a channels-last (B, Ti, Fi, Cin) image:
+    im2col -> one GEMM against Wm[c_out][(kh, kw, c_in)] -> column statistics -> normalise + activation."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps):
+        require_gpu(a, "the Conv2d prenet")
+        (kh, kw), (sh, sw), (ph, pw) = geom
+        a = a if a.is_contiguous() else a.contiguous()
+        B, Ti, Fi, Cin = a.shape
+        To, Fo = conv_out_size(Ti, kh, sh, ph), conv_out_size(Fi, kw, sw, pw)
+        Cout, K, M = w.size(0), kh * kw * Cin, B * To * Fo
+        dev, code = a.device, dcode(a)
+        g = (B, Ti, Fi, Cin, To, Fo, kh, kw, sh, sw, ph, pw)
+        col = torch.empty(M, K, dtype=a.dtype, device=dev)
+        lib.call("sc_im2col", code, _p(a), *g, _p(col), stream())
+        # (c_out, (kh, kw, c_in)) view of the weight in the compute dtype; cast here, not through the weight cache: the
+        # permuted copy is a new tensor every step
+        Wc = w.detach().permute(0, 2, 3, 1).reshape(Cout, K).to(a.dtype)
+        bn = gamma is not None
+        z = torch.empty(M, Cout, dtype=a.dtype, device=dev)
+        gemm(code, _p(col), _p(Wc), _p(z), M, Cout, K, K, K, Cout, bias=bias.detach() if (bias is not None and not bn) else None)
+        mean = rstd = None
+        if bn and training:
+            scale, shift, mean, rstd = (torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(4))
+            ws = torch.empty(lib.value("sc_bn_workspace", M, Cout), dtype=torch.uint8, device=dev)
+            lib.call("sc_bn_stats", code, _p(z), M, Cout, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum), _p(rm), _p(rv),
+                     _p(scale), _p(shift), _p(mean), _p(rstd), _p(ws), ws.numel(), stream())
+        elif bn:
+            scale, shift, mean, rstd = _bn_eval_coeffs(gamma, beta, rm, rv, eps)
+        else:
+            scale = torch.ones(Cout, dtype=torch.float32, device=dev)
+            shift = torch.zeros(Cout, dtype=torch.float32, device=dev)
+        if bn or act:
+            y = torch.empty_like(z)
+            lib.call("sc_bn_act_fwd", code, _p(z), M, Cout, _p(scale), _p(shift), act, float(slope), _p(y), stream())
+        else:
+            y = z
+        ctx.save_for_backward(col, z, w, scale, shift, mean, rstd)
+        ctx.params = (w, bias, gamma, beta)
+        ctx.meta = (g, act, slope, bn, bn and training)
+        return y.view(B, To, Fo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, z, w, scale, shift, mean, rstd = ctx.saved_tensors
+        g, act, slope, bn, batch_stats = ctx.meta
+        pw_, pb, pg, pbe = ctx.params
+        B, Ti, Fi, Cin, To, Fo, kh, kw = g[:8]
+        M, Cout = z.shape
+        K = col.size(1)
+        dev, code = z.device, dcode(z)
+        dy2 = dy.reshape(M, Cout)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dgamma = dbeta = dbias = None
+        if bn or act:
+            dz = torch.empty_like(z)
+            if bn:
+                dgamma, dbeta = _sink_or_new([pg], (Cout,), dev), _sink_or_new([pbe], (Cout,), dev)
+            ws = torch.empty(lib.value("sc_bn_workspace", M, Cout) + 12 * Cout, dtype=torch.uint8, device=dev)
+            lib.call("sc_bn_act_bwd", code, _p(z), _p(dy2), M, Cout, _p(scale), _p(shift), _p(mean), _p(rstd), 1 if batch_stats else 0, act,
+                     float(slope), _p(dz), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), stream())
+        else:
+            dz = dy2
+        side = _Side(z)
+        with side:
+            if pb is not None and not bn:
+                dWm, dbias = wgrad(code, dz, col, bias=True, bias_params=[pb])
+            else:
+                dWm = wgrad(code, dz, col)
+        da = None
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty(M, K, dtype=z.dtype, device=dev)
+            if code == BF16:  # k-contiguous product against the transposed weight ((kh, kw, c_in), c_out)
+                Wt = w.detach().permute(2, 3, 1, 0).reshape(K, Cout).to(z.dtype)
+                gemm(code, _p(dz), _p(Wt), _p(dcol), M, K, Cout, Cout, Cout, K)
+            else:
+                Wm = w.detach().permute(0, 2, 3, 1).reshape(Cout, K)
+                gemm(code, _p(dz), _p(Wm), _p(dcol), M, K, Cout, Cout, K, K, tb=1)
+            da = torch.empty(B, Ti, Fi, Cin, dtype=z.dtype, device=dev)
+            lib.call("sc_col2im", code, _p(dcol), *g, _p(da), stream())
+        side.join()
+        dw = dWm.view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+        return (da, dw, dbias, dgamma, dbeta) + (None,) * 8
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x if x.is_contiguous() else x.contiguous()
+        seed, off = DropoutState.next(x.numel(), x.device)
+        ctx.meta = (p, seed, off)
+        return _dropout_apply(x, p, seed, off)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, off = ctx.meta
+        return _dropout_apply(dy if dy.is_contiguous() else dy.contiguous(), p, seed, off), None
+
+
+def dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
+    """nn.Dropout on a compute-dtype tensor with the stateless generator (the mask is regenerated in the backward pass)."""
+    return _Dropout.apply(x, float(p)) if (training and p > 0.0) else x
+
+
+def conv_block(x, conv: torch.nn.Conv2d, bn: Optional[torch.nn.BatchNorm2d], activation: Optional[str], slope: float, training: bool,
+               first: bool):
+    """One [Conv2d -> BatchNorm2d -> activation] block of the prenet.  `first`: x is the (B, T, F) float32 feature image (one input
+    channel) and the result has the compute dtype; otherwise x is a channels-last (B, T', F', C) image."""
+    if activation not in PACT:
+        raise NotImplementedError(f"speechain_amd Conv2d prenet implements ReLU, LeakyReLU and no activation, got {activation}")
+    geom = (tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding))
+    use_batch = bn is not None and (training or not bn.track_running_stats)
+    if bn is not None:
+        if bn.momentum is None:
+            raise NotImplementedError("speechain_amd Conv2d prenet: BatchNorm2d(momentum=None) (cumulative average) is not implemented")
+        args = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        mom, eps = bn.momentum, bn.eps
+        if use_batch and bn.track_running_stats and training:
+            bn.num_batches_tracked += 1
+    else:
+        args, mom, eps = (None, None, None, None), 0.0, 0.0
+    if first:
+        return _ConvFirst.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps, compute_dtype())
+    return _ConvNext.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps)

@@ -27,6 +27,8 @@ OVERLAY = {
     "speechain.module.transformer.feed_forward": "speechain_amd.module.transformer.feed_forward",
     "speechain.module.transformer.encoder": "speechain_amd.module.transformer.encoder",
     "speechain.module.transformer.decoder": "speechain_amd.module.transformer.decoder",
+    "speechain.module.prenet.conv2d": "speechain_amd.module.prenet.conv2d",
+    "speechain.module.prenet.linear": "speechain_amd.module.prenet.linear",
     "speechain.module.postnet.token": "speechain_amd.module.postnet.token",
     "speechain.criterion.cross_entropy": "speechain_amd.criterion.cross_entropy",
     "speechain.criterion.ctc": "speechain_amd.criterion.ctc",

@@ -477,6 +477,48 @@ def g8_featnorm():
     save("g8_featnorm", **out)
 
 
+# ---- G9 Conv2dPrenet (row f2) --------------------------------------------------------------------------------------------
+
+def g9_prenet():
+    """speechain/module/prenet/conv2d.py + linear.py run as imported: training-mode output, lengths, gradients of every parameter,
+    the BatchNorm running statistics after the step, then the eval-mode output with those statistics."""
+    from speechain.module.prenet.conv2d import Conv2dPrenet
+    cases = dict(
+        bn=(dict(conv_dims=[8, 16], conv_kernel=3, conv_stride=2, conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=32), (3, 37, 20)),
+        relu=(dict(conv_dims=[8, 8], lnr_dims=[24, 16], lnr_activation="ReLU"), (3, 37, 20)),
+        asym=(dict(conv_dims=[8], conv_kernel=[3, 5], conv_stride=[2, 1], conv_batchnorm=True, lnr_dims=None), (2, 21, 20)),
+        zc=(dict(conv_dims=[8, 8], conv_activation="ReLU", lnr_dims=None, zero_centered=True), (2, 21, 20)),
+        narrow=(dict(conv_dims=[4, 4], conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=8), (2, 5, 20)),
+    )
+    out = {}
+    g = torch.Generator().manual_seed(909)
+    for tag, (conf, (B, T, Fd)) in cases.items():
+        m = Conv2dPrenet(input_size=Fd, **conf)
+        seeded_state(m, 91)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.copy_(1 + 0.1 * torch.randn(mod.weight.shape, generator=g))
+                    mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+                    mod.running_mean.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+                    mod.running_var.copy_(1 + 0.2 * torch.rand(mod.bias.shape, generator=g))
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.train()
+        x = torch.randn(B, T, Fd, generator=g) * 1.5 - 0.7
+        lens = torch.tensor([T] + [max(T - 5 * (i + 1), 1) for i in range(B - 1)])
+        y, ylen = m(x.clone(), lens.clone())
+        names, params = zip(*m.named_parameters())
+        grads = _grads([y], list(params))
+        out.update({f"{tag}.x": x, f"{tag}.len": lens, f"{tag}.out": y, f"{tag}.out_len": ylen, f"{tag}.output_size": m.output_size})
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+        out.update({f"{tag}.grad.{n}": gr for n, gr in zip(names, grads)})
+        out.update({f"{tag}.after.{k}": v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+        m.eval()
+        ye, _ = m(x.clone(), lens.clone())
+        out[f"{tag}.out_eval"] = ye
+    save("g9_prenet", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -491,3 +533,4 @@ if __name__ == "__main__":
     g6_losses()
     g7_harness()
     g8_featnorm()
+    g9_prenet()

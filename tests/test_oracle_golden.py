@@ -276,3 +276,35 @@ def test_feature_normalization_oracle_vs_reference(golden):
     _fn_close(m(*bt[2], group_ids=g["group_ids2"])[0], g["group_t.eval.y"], "group tensor eval (unseen id -> average)")
     with pytest.raises(ValueError):
         R.FeatureNormalization("global", mean_norm=False)
+
+
+# ---- g9: Conv2dPrenet (row f2) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["bn", "relu", "asym", "zc", "narrow"])
+def test_conv2d_prenet_oracle_vs_reference(golden, tag):
+    from prenet_cases import CASES, state, weighted_sum
+    g = golden("g9_prenet")
+    P = state(g, tag)
+    x, lens = g[f"{tag}.x"], g[f"{tag}.len"]
+    y, ylen, stats = R.conv2d_prenet(x, lens.clone(), P, "", **CASES[tag], training=True)
+    assert y.shape == g[f"{tag}.out"].shape and y.size(-1) == int(g[f"{tag}.output_size"])
+    assert torch.allclose(y, g[f"{tag}.out"], atol=1e-5, rtol=1e-5), float((y - g[f"{tag}.out"]).abs().max())
+    assert torch.equal(ylen, g[f"{tag}.out_len"])
+    names = [k for k, v in P.items() if v.requires_grad]
+    grads = torch.autograd.grad(weighted_sum(y), [P[k] for k in names])
+    assert len(names) == len([k for k in g if k.startswith(f"{tag}.grad.")])
+    for k, a in zip(names, grads):
+        b = g[f"{tag}.grad.{k}"]
+        assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(b.abs().max())), rtol=1e-4), (k, float((a - b).abs().max()))
+    for k, v in stats.items():
+        assert torch.allclose(v, g[f"{tag}.after.{k}"], atol=1e-6, rtol=1e-5), k
+    P2 = {k: v.detach() for k, v in P.items()}
+    P2.update(stats)
+    ye, _, _ = R.conv2d_prenet(x, lens.clone(), P2, "", **CASES[tag], training=False)
+    assert torch.allclose(ye, g[f"{tag}.out_eval"], atol=1e-5, rtol=1e-5)
+
+
+def test_conv2d_prenet_oracle_length_check():
+    """conv_padding > 0 with stride 2 trips the reference's own length check (conv2d.py:266-271; observed on the imported module)."""
+    P = {"conv.0.weight": torch.zeros(4, 1, 3, 3), "conv.0.bias": torch.zeros(4)}
+    with pytest.raises(RuntimeError, match="feature lengths"):
+        R.conv2d_prenet(torch.zeros(2, 37, 20), torch.tensor([37, 30]), P, "", conv_dims=[4], conv_padding=1, lnr_dims=None)
