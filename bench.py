@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
     ap.add_argument("--prenet-dims", default="64,64",
-                    help="conv channels of the Conv2d prenet in front of the encoder (outside the named hot path, plain torch/MIOpen). "
+                    help="conv channels of the Conv2d prenet in front of the encoder (SURVEY row f2; HIP path, FLOPs outside the named-path count). "
                          "64,64 = the transformer-wide recipes (and the module default); 512,512 = the transformer-large recipes (conv_dims = d_model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -99,8 +99,9 @@ def synth_text(seed: int, device, vocab: int = 5000):
     return text.to(device), torch.full((BATCH,), TEXT_LEN, dtype=torch.int64, device=device)
 
 
-PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + activation + Linear) is OUTSIDE the named hot path and runs on stock torch/MIOpen in "
-               "fp32. Both channel settings occur in the reference's ASR recipes for this d512/h8/ffn2048 transformer: conv_dims [64,64] "
+PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2, no bias + BatchNorm2d + LeakyReLU + Linear; SURVEY.md row f2) runs on the HIP path too "
+               "(csrc/prenet.hip + the library's GEMMs, bf16); its FLOPs are NOT counted in roofline.step_named_path. "
+               "Both channel settings occur in the reference's ASR recipes for this d512/h8/ffn2048 transformer: conv_dims [64,64] "
                "in the transformer-wide_ctc_perturb recipes (recipes/asr/librispeech/train-960/exp_cfg/960-bpe5k_transformer-wide_ctc_"
                "perturb.yaml:205-213; also the module default), conv_dims = d_model = [512,512] in the transformer-large recipes "
                "(.../train-clean-100/exp_cfg/100-bpe5k_transformer-large_lr2e-3.yaml:197-206), whose convolutions cost more FLOPs than "
@@ -108,10 +109,14 @@ PRENET_NOTE = ("Conv2dPrenet (k3 s2 x2 + BatchNorm2d + activation + Linear) is O
                "secondary: run --prenet-dims 512,512 (measured: profiles/r01_train_step_bench_prenet512.json)")
 
 
+def prenet_conf(dims):
+    """The transformer recipes' enc_prenet block (100-bpe5k_transformer-large_lr2e-3.yaml:196-206) with the given channels."""
+    return dict(conv_dims=list(dims), conv_kernel=3, conv_stride=2, conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=512)
+
+
 class ASRTrainStepWorkload:
-    """BASELINE.json configs[2] driven from waveforms: frontend -> global mean/std normalisation -> SpecAugment -> conv2d prenet (torch/MIOpen, outside the named
-    path; channels from --prenet-dims) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip ->
-    Adam (Noam), bf16 compute."""
+    """BASELINE.json configs[2] driven from waveforms: frontend -> global mean/std normalisation -> SpecAugment -> Conv2dPrenet (row f2; channels
+    from --prenet-dims) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip -> Adam (Noam), bf16 compute."""
 
     dtype = "bf16"
 
@@ -123,10 +128,11 @@ class ASRTrainStepWorkload:
                      "(BASELINE configs[2])")
         from speechain_amd import functional as Fn
         from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
-        from speechain_amd.harness import ASRTransformer, Conv2dSubsample
+        from speechain_amd.harness import ASRTransformer
         from speechain_amd.module.augment.specaug import SpecAugment
         from speechain_amd.module.frontend.speech2mel import Speech2MelSpec
         from speechain_amd.module.norm.feat_norm import FeatureNormalization
+        from speechain_amd.module.prenet.conv2d import Conv2dPrenet
 
         Fn.set_compute_dtype(torch.bfloat16)
         Fn.set_attention_probs(False)  # the train step never reads the attention maps: fused attention, no score tensors in HBM
@@ -137,7 +143,7 @@ class ASRTrainStepWorkload:
         # would keep the ranks' normalisation identical
         self.norm = FeatureNormalization(input_size=80, distributed=distributed).to(device).train()
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
-        self.prenet = Conv2dSubsample(80, self.prenet_dims, 512).to(device).train()
+        self.prenet = Conv2dPrenet(input_size=80, **prenet_conf(self.prenet_dims)).to(device).train()
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
         for m in (self.prenet, self.model):
             for p in m.parameters():
@@ -172,7 +178,7 @@ class ASRTrainStepWorkload:
         x, xlen = self.prenet(self.feat, self.flen)
         out = self.model(x, xlen, self.text, self.text_len)
         out["loss"].backward()
-        # gradients that stock torch ops produced (conv prenet, token embedding) are copied into their bucket slots HERE, inside the
+        # gradients that stock torch ops produced (token embedding, the permuted prenet weights) are copied into their bucket slots HERE, inside the
         # region that is captured: the clip below works on the flat buckets and the all-reduce ships them, so after a replay the
         # slots must hold this step's values (tests/test_bench_step_gpu.py)
         self.reducer.settle()
@@ -304,13 +310,17 @@ def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
     """The oracle's ASR step (frontend -> normalisation -> specaug -> prenet -> encoder -> decoder -> losses -> backward) on the host cores,
     on a bounded sample: ~`seconds` of steps over 4 of the 32 utterances (same per-utterance shapes), scaled to utterances/s."""
     from oracle import cpu_ref as R
-    from speechain_amd.harness import ASRTransformer, Conv2dSubsample
+    from speechain_amd.harness import ASRTransformer
+    from speechain_amd.module.prenet.conv2d import Conv2dPrenet
 
     cores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", 16)))
     torch.set_num_threads(cores)
     nb = 4
     torch.manual_seed(0)
-    prenet = Conv2dSubsample(80, tuple(prenet_dims), 512)
+    pconf = prenet_conf(prenet_dims)
+    # (the modules only supply initial weights here; the arithmetic below is the oracle's)
+    PP = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in Conv2dPrenet(input_size=80, **pconf).state_dict().items()}
     model = ASRTransformer(**ASR_MODEL)
     P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("posenc")) for k, v in model.state_dict().items()}
     P["embed.weight"] = P.pop("embed.embed.weight")
@@ -326,7 +336,7 @@ def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
         feat, flen = norm(feat, flen, epoch=1)
         d = R.specaug_draw(flen, nb, 80, **SPECAUG)
         feat = R.specaug_apply(feat, flen, d)
-        x, xlen = prenet(feat, flen)
+        x, xlen, _ = R.conv2d_prenet(feat, flen, PP, "", **pconf, training=True)
         out = R.asr_forward_loss(x, xlen, text, text_len, P, cfg)
         out["loss"].backward()
 

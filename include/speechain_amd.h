@@ -98,7 +98,7 @@ int sc_featnorm_apply(const float* feat, float* out, long long stride_b, long lo
  *   sc_conv1_apply    y[b][to][fo][c] = act(scale[c] * (w[c] . patch) + shift[c])   (no BatchNorm: scale = 1, shift = conv bias).
  *   sc_conv1_bwd      from dy (same layout as y): dw (C, KK), dgamma (C), dbeta (C; the bias gradient when mean == rstd == null).
  *                     batch_stats = 1: gradients flow through the batch statistics (training mode), needs `moments`; 0: fixed statistics. */
-long long sc_conv1_moments_workspace(int B, int To, int KH, int KW);
+long long sc_conv1_moments_workspace(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW);
 int sc_conv1_moments(const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
                      int SH, int SW, int PH, int PW, double* moments, void* workspace, long long ws_bytes, hipStream_t stream);
 int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const float* gamma, const float* beta,
@@ -107,7 +107,7 @@ int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, lon
 int sc_conv1_apply(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH,
                    int KW, int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act,
                    float slope, void* y, hipStream_t stream);
-long long sc_conv1_bwd_workspace(int B, int To, int C, int KK);
+long long sc_conv1_bwd_workspace(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW, int C);
 int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
                  int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act, float slope,
                  const void* dy, const double* moments, const float* gamma, const float* mean, const float* rstd, int batch_stats,

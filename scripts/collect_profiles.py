@@ -62,7 +62,8 @@ def main():
     print(f"--- train-step kernel stats per step ({steps} steps traced)")
     for r in csv.DictReader(open(P + "r01_train_step_kernel_stats.csv")):
         if any(k in r["Name"] for k in ("nt_dma_kernel", "gemm_bf16_kernel", "splitk_reduce", "attn_", "layernorm", "ctc_", "featnorm", "frontend_pfa",
-                                        "specaug_kernel", "reduce_parts", "cast_weights", "multi_tensor_apply", "row_lse", "ce_")):
+                                        "specaug_kernel", "reduce_parts", "cast_weights", "multi_tensor_apply", "row_lse", "ce_", "conv1_", "im2col", "col2im", "bn_",
+                                        "sum_partials")):
             print(f"  {float(r['AverageNs']) / 1e3:8.1f} us avg {int(r['Calls']) / steps:6.1f} calls/step {float(r['TotalDurationNs']) / 1e6 / steps:6.3f} ms/step  {r['Name'][:80]}")
     print("--- frontend run")
     for r in csv.DictReader(open(P + "r01_frontend_bench_kernel_stats.csv")):

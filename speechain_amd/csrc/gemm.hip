@@ -1270,7 +1270,8 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // K = 512 21.1 -> 20.3 us -- hence the threshold of 192.  [Tried and rejected: 128 x 128 instead of 256 x 256 tiles for the launches with a VALU-heavy
       // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
-      if (big >= 160) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
+      // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
+      if (big >= 160 && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
       if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
       g_last_gemm_kernel = 1;
       return launch_dma<2, 2, 2>(a, nb, stream);

@@ -90,15 +90,39 @@ __device__ __forceinline__ void st4(T* p, const float (&v)[4], bool vec, int n) 
 // grid = row groups; a workgroup stages the KH input rows of one output row in LDS, thread q < KK*KK + KK owns one entry and
 // walks the Fo positions of the row.  Partials [group][KK*KK + KK] in float64; conv1_moments_finish sums them in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------------------------
+// out[n] = sum_g partial[g][n] in float64: 1024 threads = 32 columns x 32 row lanes, fixed order (deterministic)
+template <typename TIn>
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const TIn* partial, int G, long long N, double* out) {
+  __shared__ double red[32][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const long long n = (long long)blockIdx.x * 32 + cx;
+  double s = 0.0;
+  if (n < N)
+    for (int g = ry; g < G; g += 32) s += (double)partial[(long long)g * N + n];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    double t = 0.0;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) t += red[l][cx];
+    out[n] = t;
+  }
+}
+
+// A tile = R consecutive output rows of one image; its (R-1)*SH + KH input rows are staged in LDS once.  A workgroup walks
+// `tiles_per_group` tiles.
+struct Tiling {
+  int R, tiles_per_b, tiles_per_group, groups;
+};
+
 constexpr int MAX_TAPS = 15;  // KH*KW of the first block (9 in every recipe): KK*KK + KK <= 256 entries, one thread each
 
-__global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long long sb, long long st, Geo g, int rows_per_group,
-                                                            double* partial) {
-  extern __shared__ float rows[];  // [KH][Fi + 2*PW] (zero borders)
+__global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long long sb, long long st, Geo g, Tiling tl, double* partial) {
+  extern __shared__ float rows[];  // [(R-1)*SH + KH][Fi + 2*PW] (zero borders)
   const int KK = g.KH * g.KW, NE = KK * KK + KK;
   const int W = g.Fi + 2 * g.PW;
   const int q = threadIdx.x;
-  int oi = 0, oj = 0;  // LDS offsets of the two taps of this entry, relative to fo * SW
+  int oi = 0, oj = 0;  // LDS offsets of the two taps of this entry, relative to the patch origin
   bool pair = false;
   if (q < KK * KK) {
     const int i = q / KK, j = q % KK;
@@ -110,33 +134,28 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long
     oi = (j / g.KW) * W + (j % g.KW);
   }
   double acc = 0.0;
-  const long long nrows = (long long)g.B * g.To;
-  const long long r0 = (long long)blockIdx.x * rows_per_group;
-  for (long long r = r0; r < r0 + rows_per_group && r < nrows; ++r) {
-    const int b = (int)(r / g.To), to = (int)(r % g.To);
+  const int ntiles = g.B * tl.tiles_per_b;
+  const int nin = (tl.R - 1) * g.SH + g.KH;
+  for (int tile = blockIdx.x * tl.tiles_per_group; tile < (blockIdx.x + 1) * tl.tiles_per_group && tile < ntiles; ++tile) {
+    const int b = tile / tl.tiles_per_b, to0 = (tile % tl.tiles_per_b) * tl.R;
+    const int nr = min(tl.R, g.To - to0);
     __syncthreads();
-    for (int i = threadIdx.x; i < g.KH * W; i += blockDim.x) {
-      const int kh = i / W, f = i % W - g.PW;
-      const int t = to * g.SH - g.PH + kh;
+    for (int i = threadIdx.x; i < nin * W; i += blockDim.x) {
+      const int r = i / W, f = i % W - g.PW;
+      const int t = to0 * g.SH - g.PH + r;
       rows[i] = (t >= 0 && t < g.Ti && f >= 0 && f < g.Fi) ? x[(long long)b * sb + (long long)t * st + f] : 0.f;
     }
     __syncthreads();
-    if (q < NE) {
-      for (int fo = 0; fo < g.Fo; ++fo) {  // float64 throughout: the variance is a difference of these moments
-        const double a = (double)rows[fo * g.SW + oi];
-        acc += pair ? a * (double)rows[fo * g.SW + oj] : a;
+    if (q < NE)
+      for (int ro = 0; ro < nr; ++ro) {
+        const float* base = rows + ro * g.SH * W;
+        for (int fo = 0; fo < g.Fo; ++fo) {  // float64 throughout: the variance is a difference of these moments
+          const double a = (double)base[fo * g.SW + oi];
+          acc += pair ? a * (double)base[fo * g.SW + oj] : a;
+        }
       }
-    }
   }
   if (q < NE) partial[(long long)blockIdx.x * NE + q] = acc;
-}
-
-__global__ void conv1_moments_finish_kernel(const double* partial, int groups, int NE, double* moments) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= NE) return;
-  double s = 0.0;
-  for (int i = 0; i < groups; ++i) s += partial[(long long)i * NE + q];
-  moments[q] = s;
 }
 
 // BatchNorm2d coefficients of channel c from the moments (training): scale = gamma * rstd, shift = beta - mean * scale; the
@@ -169,11 +188,13 @@ __global__ void conv1_bn_coeffs_kernel(const double* moments, const float* w, in
   if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (count > 1.0 ? count / (count - 1.0) : 1.0));
 }
 
-// First block, output: y[b][to][fo][c] = act(scale_c * (w_c . patch) + shift_c), channels-last.  A workgroup takes `rows_per_group`
-// output rows; per row the KH input rows go to LDS; a thread owns 4 consecutive channels (their KK x 4 weights stay in registers)
+// First block, output: y[b][to][fo][c] = act(scale_c * (w_c . patch) + shift_c), channels-last.  A workgroup walks tiles of R output
+// rows whose input rows are staged in LDS once; a thread owns 4 consecutive channels (their KK x 4 weights stay in registers)
 // and strides over fo.  grid.y tiles the channels in slabs of 1024.
 #define SC_CONV1_THREAD_SETUP(SLAB)                                                                                         \
-  const int KK = g.KH * g.KW, W = g.Fi + 2 * g.PW;                                                                          \
+  constexpr int NT = KKT ? KKT : MAX_TAPS; /* register arrays sized for the taps that exist */                              \
+  const int KK = KKT ? KKT : g.KH * g.KW;  /* KKT = 9: the per-tap guards of the unrolled loops fold away */                \
+  const int W = g.Fi + 2 * g.PW;                                                                                            \
   const int c0 = blockIdx.y * (SLAB);                                                                                       \
   const int CS = min((SLAB), C - c0);                                                                                       \
   const int CSp = (CS + 3) & ~3;                                                                                            \
@@ -189,103 +210,123 @@ __global__ void conv1_bn_coeffs_kernel(const double* moments, const float* w, in
     sc[i] = (live && i < nc) ? scale[c + i] : 0.f;                                                                          \
     sh[i] = (live && i < nc) ? shift[c + i] : 0.f;                                                                          \
   }                                                                                                                         \
-  int toff[MAX_TAPS];                                                                                                       \
-  float wr[MAX_TAPS][4];                                                                                                    \
-  _Pragma("unroll") for (int k = 0; k < MAX_TAPS; ++k) {                                                                    \
+  int toff[NT];                                                                                                       \
+  float wr[NT][4];                                                                                                    \
+  _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                                    \
     toff[k] = k < KK ? (k / g.KW) * W + (k % g.KW) : 0;                                                                     \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) wr[k][i] = (k < KK && live && i < nc) ? w[(long long)(c + i) * KK + k] : 0.f; \
   }
 
-#define SC_CONV1_STAGE_ROWS()                                                                                               \
+#define SC_CONV1_STAGE_TILE()                                                                                               \
+  const int b = tile / tl.tiles_per_b, to0 = (tile % tl.tiles_per_b) * tl.R;                                                \
+  const int npos = min(tl.R, g.To - to0) * g.Fo;                                                                            \
   __syncthreads();                                                                                                          \
-  for (int i = threadIdx.x; i < g.KH * W; i += blockDim.x) {                                                                \
-    const int kh = i / W, f = i % W - g.PW;                                                                                 \
-    const int t = to * g.SH - g.PH + kh;                                                                                    \
+  for (int i = threadIdx.x; i < nin * W; i += blockDim.x) {                                                                 \
+    const int r = i / W, f = i % W - g.PW;                                                                                  \
+    const int t = to0 * g.SH - g.PH + r;                                                                                    \
     rows[i] = (t >= 0 && t < g.Ti && f >= 0 && f < g.Fi) ? x[(long long)b * sb + (long long)t * st + f] : 0.f;              \
   }                                                                                                                         \
   __syncthreads();
 
-template <typename T>
+template <typename T, int KKT>
 __global__ __launch_bounds__(256) void conv1_apply_kernel(const float* x, long long sb, long long st, Geo g, const float* w, int C,
                                                           const float* scale, const float* shift, int act, float slope, T* y,
-                                                          int rows_per_group) {
-  extern __shared__ float rows[];  // [KH][W]
+                                                          Tiling tl) {
+  extern __shared__ float rows[];  // [(R-1)*SH + KH][W]
   SC_CONV1_THREAD_SETUP(1024)
-  const long long nrows = (long long)g.B * g.To;
-  const long long r0 = (long long)blockIdx.x * rows_per_group;
-  for (long long r = r0; r < r0 + rows_per_group && r < nrows; ++r) {
-    const int b = (int)(r / g.To), to = (int)(r % g.To);
-    SC_CONV1_STAGE_ROWS()
+  const int ntiles = g.B * tl.tiles_per_b;
+  const int nin = (tl.R - 1) * g.SH + g.KH;
+  for (int tile = blockIdx.x * tl.tiles_per_group; tile < (blockIdx.x + 1) * tl.tiles_per_group && tile < ntiles; ++tile) {
+    SC_CONV1_STAGE_TILE()
     if (!live) continue;
-    for (int fo = lane; fo < g.Fo; fo += lanes) {
+    const long long r = (long long)b * g.To + to0;  // first output row of the tile
+    for (int pos = lane; pos < npos; pos += lanes) {
+      const int ro = pos / g.Fo, fo = pos - ro * g.Fo;
+      const int origin = ro * g.SH * W + fo * g.SW;
       float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS; ++k)
+      for (int k = 0; k < NT; ++k)
         if (k < KK) {
-          const float p = rows[toff[k] + fo * g.SW];
+          const float p = rows[toff[k] + origin];
 #pragma unroll
           for (int i = 0; i < 4; ++i) z[i] = fmaf(p, wr[k][i], z[i]);
         }
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = pact(fmaf(sc[i], z[i], sh[i]), act, slope);
-      st4<T>(y + (r * g.Fo + fo) * (long long)C + c, o, vec, nc);
+      st4<T>(y + (r * g.Fo + pos) * (long long)C + c, o, vec, nc);
     }
   }
 }
 
 // First block, backward: partial[group][c][KK + 1] = (sum_pos g * patch_k (k < KK), sum_pos g) with g = dy * act'(scale z + shift),
 // z recomputed from the staged rows.  Same work split as conv1_apply_kernel (256-channel slabs); the lanes of a quad meet in LDS.
-template <typename T>
+template <typename T, int KKT>
 __global__ __launch_bounds__(256) void conv1_bwd_reduce_kernel(const float* x, long long sb, long long st, Geo g, const float* w, int C,
                                                                const float* scale, const float* shift, int act, float slope,
-                                                               const T* dy, int rows_per_group, float* partial) {
-  extern __shared__ float rows[];  // [KH][W], then [lanes][CSp] scratch for the final reduction
+                                                               const T* dy, Tiling tl, float* partial) {
+  extern __shared__ float rows[];  // [(R-1)*SH + KH][W], then [lanes][CSp] scratch for the final reduction
   SC_CONV1_THREAD_SETUP(256)
-  float* red = rows + g.KH * W;
-  float G[MAX_TAPS + 1][4];
+  const int ntiles = g.B * tl.tiles_per_b;
+  const int nin = (tl.R - 1) * g.SH + g.KH;
+  float* red = rows + nin * W;
+  float G[NT + 1][4];
 #pragma unroll
-  for (int k = 0; k <= MAX_TAPS; ++k) G[k][0] = G[k][1] = G[k][2] = G[k][3] = 0.f;
-  const long long nrows = (long long)g.B * g.To;
-  const long long r0 = (long long)blockIdx.x * rows_per_group;
-  for (long long r = r0; r < r0 + rows_per_group && r < nrows; ++r) {
-    const int b = (int)(r / g.To), to = (int)(r % g.To);
-    SC_CONV1_STAGE_ROWS()
+  for (int k = 0; k <= NT; ++k) G[k][0] = G[k][1] = G[k][2] = G[k][3] = 0.f;
+  for (int tile = blockIdx.x * tl.tiles_per_group; tile < (blockIdx.x + 1) * tl.tiles_per_group && tile < ntiles; ++tile) {
+    SC_CONV1_STAGE_TILE()
     if (!live) continue;
-    for (int fo = lane; fo < g.Fo; fo += lanes) {
-      float z[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long r = (long long)b * g.To + to0;
+    // four positions per trip, their dy loads issued before any arithmetic: with ~170 VGPRs only two waves share a SIMD, so a
+    // load that is waited for immediately costs a full memory round trip per position
+    for (int pos0 = lane; pos0 < npos; pos0 += 4 * lanes) {
+      float d[4][4];
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS; ++k)
-        if (k < KK) {
-          const float p = rows[toff[k] + fo * g.SW];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) z[i] = fmaf(p, wr[k][i], z[i]);
+      for (int u = 0; u < 4; ++u) {
+        const int pos = pos0 + u * lanes;
+        if (pos < npos) {
+          ld4<T>(dy + (r * g.Fo + pos) * (long long)C + c, d[u], vec, nc);
+        } else {
+          d[u][0] = d[u][1] = d[u][2] = d[u][3] = 0.f;
         }
-      float d[4];
-      ld4<T>(dy + (r * g.Fo + fo) * (long long)C + c, d, vec, nc);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) d[i] *= pact_grad(fmaf(sc[i], z[i], sh[i]), act, slope);
+      for (int u = 0; u < 4; ++u) {
+        const int pos = min(pos0 + u * lanes, npos - 1);  // (a clamped position contributes d = 0)
+        const int ro = pos / g.Fo, fo = pos - ro * g.Fo;
+        const int origin = ro * g.SH * W + fo * g.SW;
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS; ++k)
-        if (k < KK) {
-          const float p = rows[toff[k] + fo * g.SW];
+        for (int k = 0; k < NT; ++k)
+          if (k < KK) {
+            const float p = rows[toff[k] + origin];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) G[k][i] = fmaf(d[i], p, G[k][i]);
-        }
+            for (int i = 0; i < 4; ++i) z[i] = fmaf(p, wr[k][i], z[i]);
+          }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) G[MAX_TAPS][i] += d[i];
+        for (int i = 0; i < 4; ++i) d[u][i] *= pact_grad(fmaf(sc[i], z[i], sh[i]), act, slope);
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+          if (k < KK) {
+            const float p = rows[toff[k] + origin];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) G[k][i] = fmaf(d[u][i], p, G[k][i]);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[NT][i] += d[u][i];
+      }
     }
   }
   // reduce the lanes of every quad through LDS, one tap at a time (fixed order)
   for (int k = 0; k <= KK; ++k) {
-    const int kk = k < KK ? k : MAX_TAPS;
+    const int kk = k < KK ? k : NT;
     __syncthreads();
     if (live) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v = 0.f;
 #pragma unroll
-        for (int q = 0; q <= MAX_TAPS; ++q)
+        for (int q = 0; q <= NT; ++q)
           if (q == kk) v = G[q][i];
         red[lane * CSp + cq * 4 + i] = v;
       }
@@ -300,26 +341,21 @@ __global__ __launch_bounds__(256) void conv1_bwd_reduce_kernel(const float* x, l
 }
 
 // dW[c][k], dgamma, dbeta of the first block from the reduced G, sum g and the forward moments (see the file header).
-// Gsum: [C][KK + 1] float64 scratch (the group sums).
-__global__ void conv1_bwd_finish_kernel(const float* partial, int groups, double* Gsum, const double* moments, const float* w, int C, int KK,
-                                        double count, const float* gamma, const float* mean, const float* rstd, int batch_stats,
-                                        float* dw, float* dgamma, float* dbeta) {
+// Gsum: [C][KK + 1] float64 (sum_partials_kernel over the groups).
+__global__ void conv1_bwd_finish_kernel(const double* Gsum, const double* moments, const float* w, int C, int KK, double count,
+                                        const float* gamma, const float* mean, const float* rstd, int batch_stats, float* dw,
+                                        float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double* G = Gsum + (long long)c * (KK + 1);
-  double sgz = 0.0;
-  for (int k = 0; k <= KK; ++k) {
-    double s = 0.0;
-    for (int i = 0; i < groups; ++i) s += (double)partial[((long long)i * C + c) * (KK + 1) + k];
-    G[k] = s;
-    if (k < KK) sgz += (double)w[c * KK + k] * s;
-  }
+  const double* G = Gsum + (long long)c * (KK + 1);
   const double sg = G[KK];
   if (!mean) {  // no BatchNorm: z = w.p + bias
     for (int k = 0; k < KK; ++k) dw[c * KK + k] = (float)G[k];
     if (dbeta) dbeta[c] = (float)sg;  // the bias gradient
     return;
   }
+  double sgz = 0.0;
+  for (int k = 0; k < KK; ++k) sgz += (double)w[c * KK + k] * G[k];
   const double m = mean[c], rs = rstd[c], ga = gamma ? (double)gamma[c] : 1.0;
   const double dg = rs * (sgz - m * sg);  // sum g * xhat
   if (dgamma) dgamma[c] = (float)dg;
@@ -457,19 +493,15 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* z, const T* 
   }
 }
 
-// forward finish: batch mean / biased variance -> scale, shift, saved mean / rstd; running statistics updated in place
-__global__ void bn_stats_finish_kernel(const float* partial, int slabs, int C, double count, const float* gamma, const float* beta,
-                                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                       float* mean, float* rstd) {
+// forward finish from sums[0][c] = sum z, sums[1][c] = sum z^2 (float64): batch mean / biased variance -> scale, shift, saved
+// mean / rstd; running statistics updated in place
+__global__ void bn_stats_finish_kernel(const double* sums, int C, double count, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                                       float* rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < slabs; ++i) {
-    s += (double)partial[((long long)i * 2) * C + c];
-    q += (double)partial[((long long)i * 2 + 1) * C + c];
-  }
-  const double m = s / count;
-  double var = q / count - m * m;
+  const double m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
   if (var < 0.0) var = 0.0;
   const double rs = 1.0 / sqrt(var + (double)eps);
   const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
@@ -481,17 +513,14 @@ __global__ void bn_stats_finish_kernel(const float* partial, int slabs, int C, d
   if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (count > 1.0 ? count / (count - 1.0) : 1.0));
 }
 
-// backward finish: dgamma = sum g*xhat, dbeta = sum g and the per-column coefficients of dz = ca*g + cb*z + cc
+// backward finish from sums[0][c] = sum g, sums[1][c] = sum g*z: dgamma = sum g*xhat, dbeta = sum g and the per-column coefficients of
+// dz = ca*g + cb*z + cc
 //   batch statistics: dz = gamma*rstd * (g - sum g / N - xhat * dgamma / N);  fixed (running) statistics or no BatchNorm: dz = scale * g
-__global__ void bn_bwd_finish_kernel(const float* partial, int slabs, int C, double count, const float* scale, const float* mean,
-                                     const float* rstd, int batch_stats, float* dgamma, float* dbeta, float* coef) {
+__global__ void bn_bwd_finish_kernel(const double* sums, int C, double count, const float* scale, const float* mean, const float* rstd,
+                                     int batch_stats, float* dgamma, float* dbeta, float* coef) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double sg = 0.0, sgz = 0.0;
-  for (int i = 0; i < slabs; ++i) {
-    sg += (double)partial[((long long)i * 2) * C + c];
-    sgz += (double)partial[((long long)i * 2 + 1) * C + c];
-  }
+  const double sg = sums[c], sgz = sums[C + c];
   const double a = (double)scale[c];  // gamma * rstd (or 1 without BatchNorm)
   double dg = 0.0;
   if (mean) {
@@ -550,16 +579,24 @@ int geo_ok(const Geo& g) {
          g.Ti + 2 * g.PH >= g.KH && g.Fi + 2 * g.PW >= g.KW;
 }
 
-int row_groups(long long nrows, int* rows_per_group) {
-  long long rpg = (nrows + 2047) / 2048;  // <= 2048 workgroups: ~8 per CU
-  if (rpg < 1) rpg = 1;
-  *rows_per_group = (int)rpg;
-  return (int)((nrows + rpg - 1) / rpg);
+Tiling tiling(const Geo& g) {
+  Tiling t;
+  t.R = std::min(8, g.To);
+  while (t.R > 1 && (size_t)((t.R - 1) * g.SH + g.KH) * (g.Fi + 2 * g.PW) * sizeof(float) > 32768) --t.R;
+  t.tiles_per_b = (g.To + t.R - 1) / t.R;
+  const long long tiles = (long long)g.B * t.tiles_per_b;
+  t.tiles_per_group = (int)std::max(1LL, (tiles + 1023) / 1024);  // <= 1024 workgroups (4 per CU), <= 1024 partial rows
+  t.groups = (int)((tiles + t.tiles_per_group - 1) / t.tiles_per_group);
+  return t;
 }
+
+size_t tile_lds(const Geo& g, const Tiling& t) { return (size_t)((t.R - 1) * g.SH + g.KH) * (g.Fi + 2 * g.PW) * sizeof(float); }
+
+Geo geo_of(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW) { return Geo{B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW}; }
 
 int col_slabs(long long M, long long* rows_per_slab) {
   long long slabs = (M + 63) / 64;  // >= 64 rows (8 per row lane) per slab
-  if (slabs > 1024) slabs = 1024;
+  if (slabs > 512) slabs = 512;
   if (slabs < 1) slabs = 1;
   *rows_per_slab = (M + slabs - 1) / slabs;
   return (int)((M + *rows_per_slab - 1) / *rows_per_slab);
@@ -579,11 +616,12 @@ unsigned flat_grid(long long items) {
   SC_CHECK_ARG(geo_ok(g), "%s: inconsistent geometry B=%d in=%dx%d out=%dx%d k=%dx%d s=%dx%d p=%dx%d", __func__, B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW)
 
 // ---- first block -------------------------------------------------------------------------------------------------------------------
-SC_API long long sc_conv1_moments_workspace(int B, int To, int KH, int KW) {
-  int rpg;
-  const int groups = row_groups((long long)B * To, &rpg);
+// (workspace sizes depend on the tiling, which depends on the whole geometry: the *_workspace functions take it all)
+SC_API long long sc_conv1_moments_workspace(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW) {
+  const Geo g = geo_of(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW);
+  if (!geo_ok(g)) return 0;
   const long long NE = (long long)KH * KW * KH * KW + KH * KW;
-  return groups * NE * (long long)sizeof(double);
+  return tiling(g).groups * NE * (long long)sizeof(double);
 }
 
 SC_API int sc_conv1_moments(const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
@@ -591,17 +629,17 @@ SC_API int sc_conv1_moments(const float* x, long long stride_b, long long stride
   SC_CHECK_ARG(x && moments && workspace, "sc_conv1_moments: null pointer");
   SC_GEO(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW);
   const int KK = KH * KW, NE = KK * KK + KK;
-  SC_CHECK_ARG(KK <= 15, "sc_conv1_moments: at most 15 taps (KH*KW = %d): one thread per entry of the %d x %d moment matrix", KK, KK, KK);
+  SC_CHECK_ARG(KK <= MAX_TAPS, "sc_conv1_moments: at most %d taps (KH*KW = %d): one thread per entry of the moment matrix", MAX_TAPS, KK);
   SC_CHECK_ARG(stride_t >= Fi && stride_b >= (long long)Ti * stride_t, "sc_conv1_moments: strides too small");
-  SC_CHECK_ARG(ws_bytes >= sc_conv1_moments_workspace(B, To, KH, KW), "sc_conv1_moments: workspace too small");
-  int rpg;
-  const int groups = row_groups((long long)B * To, &rpg);
-  const size_t lds = (size_t)KH * (Fi + 2 * PW) * sizeof(float);
+  const Tiling tl = tiling(g);
+  SC_CHECK_ARG(ws_bytes >= (long long)tl.groups * NE * (long long)sizeof(double), "sc_conv1_moments: workspace too small");
+  const size_t lds = tile_lds(g, tl);
   SC_CHECK_ARG(lds <= 60000, "sc_conv1_moments: %d input rows of %d values do not fit LDS", KH, Fi + 2 * PW);
-  hipLaunchKernelGGL(conv1_moments_kernel, dim3(groups), dim3(256), lds, stream, x, stride_b, stride_t, g, rpg, (double*)workspace);
+  hipLaunchKernelGGL(conv1_moments_kernel, dim3(tl.groups), dim3(256), lds, stream, x, stride_b, stride_t, g, tl, (double*)workspace);
   SC_LAUNCH_CHECK("conv1_moments_kernel");
-  hipLaunchKernelGGL(conv1_moments_finish_kernel, dim3(sc_cdiv(NE, 256)), dim3(256), 0, stream, (const double*)workspace, groups, NE, moments);
-  SC_LAUNCH_CHECK("conv1_moments_finish_kernel");
+  hipLaunchKernelGGL(sum_partials_kernel<double>, dim3(sc_cdiv(NE, 32)), dim3(1024), 0, stream, (const double*)workspace, tl.groups,
+                     (long long)NE, moments);
+  SC_LAUNCH_CHECK("sum_partials_kernel");
   return SC_OK;
 }
 
@@ -609,7 +647,7 @@ SC_API int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int 
                               float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
                               float* rstd, hipStream_t stream) {
   SC_CHECK_ARG(moments && w && scale && shift && mean && rstd, "sc_conv1_bn_coeffs: null pointer");
-  SC_CHECK_ARG(C >= 1 && KK >= 1 && KK <= 15 && count >= 1, "sc_conv1_bn_coeffs: bad sizes C=%d KK=%d count=%lld", C, KK, count);
+  SC_CHECK_ARG(C >= 1 && KK >= 1 && KK <= MAX_TAPS && count >= 1, "sc_conv1_bn_coeffs: bad sizes C=%d KK=%d count=%lld", C, KK, count);
   hipLaunchKernelGGL(conv1_bn_coeffs_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, moments, w, C, KK, (double)count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, mean, rstd);
   SC_LAUNCH_CHECK("conv1_bn_coeffs_kernel");
@@ -625,25 +663,27 @@ SC_API int sc_conv1_apply(int dtype, const float* x, long long stride_b, long lo
   SC_GEO(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW);
   SC_CHECK_ARG(KH * KW <= MAX_TAPS, "sc_conv1_apply: at most %d taps", MAX_TAPS);
   SC_CHECK_ARG(stride_t >= Fi && stride_b >= (long long)Ti * stride_t, "sc_conv1_apply: strides too small");
-  int rpg;
-  const int groups = row_groups((long long)B * To, &rpg);
-  const size_t lds = (size_t)KH * (Fi + 2 * PW) * sizeof(float);
+  const Tiling tl = tiling(g);
+  const size_t lds = tile_lds(g, tl);
   SC_CHECK_ARG(lds <= 60000, "sc_conv1_apply: %d input rows of %d values do not fit LDS", KH, Fi + 2 * PW);
-  const dim3 grid(groups, sc_cdiv(C, 1024));
-  if (dtype == 0)
-    hipLaunchKernelGGL(conv1_apply_kernel<float>, grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act, slope,
-                       (float*)y, rpg);
-  else
-    hipLaunchKernelGGL(conv1_apply_kernel<unsigned short>, grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act,
-                       slope, (unsigned short*)y, rpg);
+  const dim3 grid(tl.groups, sc_cdiv(C, 1024));
+#define SC_LAUNCH_APPLY(T, KKT) \
+  hipLaunchKernelGGL((conv1_apply_kernel<T, KKT>), grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act, slope, (T*)y, tl)
+  if (dtype == 0) {
+    if (KH * KW == 9) SC_LAUNCH_APPLY(float, 9); else SC_LAUNCH_APPLY(float, 0);
+  } else {
+    if (KH * KW == 9) SC_LAUNCH_APPLY(unsigned short, 9); else SC_LAUNCH_APPLY(unsigned short, 0);
+  }
+#undef SC_LAUNCH_APPLY
   SC_LAUNCH_CHECK("conv1_apply_kernel");
   return SC_OK;
 }
 
-SC_API long long sc_conv1_bwd_workspace(int B, int To, int C, int KK) {
-  int rpg;
-  const int groups = row_groups((long long)B * To, &rpg);
-  return (long long)groups * C * (KK + 1) * (long long)sizeof(float) + (long long)C * (KK + 1) * (long long)sizeof(double);
+SC_API long long sc_conv1_bwd_workspace(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW, int C) {
+  const Geo g = geo_of(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW);
+  if (!geo_ok(g)) return 0;
+  const long long n = (long long)C * (KH * KW + 1);
+  return n * (long long)sizeof(double) + (long long)tiling(g).groups * n * (long long)sizeof(float);
 }
 
 SC_API int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
@@ -659,23 +699,30 @@ SC_API int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long
   const int KK = KH * KW;
   SC_CHECK_ARG(KK <= MAX_TAPS, "sc_conv1_bwd: at most %d taps", MAX_TAPS);
   SC_CHECK_ARG(stride_t >= Fi && stride_b >= (long long)Ti * stride_t, "sc_conv1_bwd: strides too small");
-  SC_CHECK_ARG(ws_bytes >= sc_conv1_bwd_workspace(B, To, C, KK), "sc_conv1_bwd: workspace too small");
-  int rpg;
-  const int groups = row_groups((long long)B * To, &rpg);
+  SC_CHECK_ARG(ws_bytes >= sc_conv1_bwd_workspace(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW, C), "sc_conv1_bwd: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_conv1_bwd: workspace must be 8-byte aligned");
+  const Tiling tl = tiling(g);
+  const long long n = (long long)C * (KK + 1);
+  double* gsum = (double*)workspace;
+  float* partial = (float*)(gsum + n);
   const int CSp = (std::min(C, 256) + 3) & ~3;
   const int lanes = std::max(1, 256 / (CSp / 4));
-  const size_t lds = ((size_t)KH * (Fi + 2 * PW) + (size_t)lanes * CSp) * sizeof(float);
+  const size_t lds = tile_lds(g, tl) + (size_t)lanes * CSp * sizeof(float);
   SC_CHECK_ARG(lds <= 60000, "sc_conv1_bwd: input rows + reduction scratch (%zu bytes) do not fit LDS", lds);
-  const dim3 grid(groups, sc_cdiv(C, 256));
-  if (dtype == 0)
-    hipLaunchKernelGGL(conv1_bwd_reduce_kernel<float>, grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act, slope,
-                       (const float*)dy, rpg, (float*)workspace);
-  else
-    hipLaunchKernelGGL(conv1_bwd_reduce_kernel<unsigned short>, grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act,
-                       slope, (const unsigned short*)dy, rpg, (float*)workspace);
+  const dim3 grid(tl.groups, sc_cdiv(C, 256));
+#define SC_LAUNCH_REDUCE(T, KKT)                                                                                                          \
+  hipLaunchKernelGGL((conv1_bwd_reduce_kernel<T, KKT>), grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act, slope, \
+                     (const T*)dy, tl, partial)
+  if (dtype == 0) {
+    if (KK == 9) SC_LAUNCH_REDUCE(float, 9); else SC_LAUNCH_REDUCE(float, 0);
+  } else {
+    if (KK == 9) SC_LAUNCH_REDUCE(unsigned short, 9); else SC_LAUNCH_REDUCE(unsigned short, 0);
+  }
+#undef SC_LAUNCH_REDUCE
   SC_LAUNCH_CHECK("conv1_bwd_reduce_kernel");
-  double* gsum = (double*)((char*)workspace + (long long)groups * C * (KK + 1) * (long long)sizeof(float));
-  hipLaunchKernelGGL(conv1_bwd_finish_kernel, dim3(sc_cdiv(C, 64)), dim3(64), 0, stream, (const float*)workspace, groups, gsum, moments, w, C, KK,
+  hipLaunchKernelGGL(sum_partials_kernel<float>, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, stream, (const float*)partial, tl.groups, n, gsum);
+  SC_LAUNCH_CHECK("sum_partials_kernel");
+  hipLaunchKernelGGL(conv1_bwd_finish_kernel, dim3(sc_cdiv(C, 64)), dim3(64), 0, stream, (const double*)gsum, moments, w, C, KK,
                      (double)B * To * Fo, gamma, mean, rstd, batch_stats, dw, dgamma, dbeta);
   SC_LAUNCH_CHECK("conv1_bwd_finish_kernel");
   return SC_OK;
@@ -725,10 +772,10 @@ SC_API int sc_col2im(int dtype, const void* dcol, int B, int Ti, int Fi, int C, 
 }
 
 // ---- BatchNorm over the rows of an (M, C) matrix + activation ------------------------------------------------------------------------
-SC_API long long sc_bn_workspace(long long M, int C) {
+SC_API long long sc_bn_workspace(long long M, int C) {  // [2][C] float64 sums, then [slabs][2][C] float partials
   long long rps;
   const int slabs = col_slabs(M, &rps);
-  return (long long)slabs * 2 * C * (long long)sizeof(float);
+  return 2LL * C * (long long)sizeof(double) + (long long)slabs * 2 * C * (long long)sizeof(float);
 }
 
 SC_API int sc_bn_stats(int dtype, const void* z, long long M, int C, const float* gamma, const float* beta, float eps, float momentum,
@@ -739,18 +786,23 @@ SC_API int sc_bn_stats(int dtype, const void* z, long long M, int C, const float
   SC_CHECK_ARG(M >= 1 && C >= 1, "sc_bn_stats: bad sizes M=%lld C=%d", M, C);
   SC_CHECK_ARG((uintptr_t)z % 16 == 0, "sc_bn_stats: z must be 16-byte aligned");
   SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C), "sc_bn_stats: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_stats: workspace must be 8-byte aligned");
   long long rps;
   const int slabs = col_slabs(M, &rps);
+  double* sums = (double*)workspace;
+  float* partial = (float*)(sums + 2LL * C);
   const dim3 grid(sc_cdiv(C, 128), slabs);
   if (dtype == 0)
     hipLaunchKernelGGL((bn_colreduce_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)z, (const float*)nullptr, M, C, nullptr,
-                       nullptr, 0, 0.f, rps, (float*)workspace);
+                       nullptr, 0, 0.f, rps, partial);
   else
     hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 0>), grid, dim3(256), 0, stream, (const unsigned short*)z,
-                       (const unsigned short*)nullptr, M, C, nullptr, nullptr, 0, 0.f, rps, (float*)workspace);
+                       (const unsigned short*)nullptr, M, C, nullptr, nullptr, 0, 0.f, rps, partial);
   SC_LAUNCH_CHECK("bn_colreduce_kernel<0>");
-  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const float*)workspace, slabs, C, (double)M, gamma,
-                     beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
+  hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sc_cdiv(2 * C, 32)), dim3(1024), 0, stream, (const float*)partial, slabs, 2LL * C, sums);
+  SC_LAUNCH_CHECK("sum_partials_kernel");
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const double*)sums, C, (double)M, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, mean, rstd);
   SC_LAUNCH_CHECK("bn_stats_finish_kernel");
   return SC_OK;
 }
@@ -781,9 +833,11 @@ SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, 
   SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_bn_act_bwd: mean and rstd come together");
   SC_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dz % 16 == 0), "sc_bn_act_bwd: buffers must be 16-byte aligned");
   SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C) + 3LL * C * (long long)sizeof(float), "sc_bn_act_bwd: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_act_bwd: workspace must be 8-byte aligned");
   long long rps;
   const int slabs = col_slabs(M, &rps);
-  float* partial = (float*)workspace;
+  double* sums = (double*)workspace;
+  float* partial = (float*)(sums + 2LL * C);
   float* coef = partial + (long long)slabs * 2 * C;
   const dim3 grid(sc_cdiv(C, 128), slabs);
   if (dtype == 0)
@@ -793,8 +847,10 @@ SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, 
     hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 1>), grid, dim3(256), 0, stream, (const unsigned short*)z, (const unsigned short*)dy,
                        M, C, scale, shift, act, slope, rps, partial);
   SC_LAUNCH_CHECK("bn_colreduce_kernel<1>");
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const float*)partial, slabs, C, (double)M, scale, mean,
-                     rstd, batch_stats, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sc_cdiv(2 * C, 32)), dim3(1024), 0, stream, (const float*)partial, slabs, 2LL * C, sums);
+  SC_LAUNCH_CHECK("sum_partials_kernel");
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const double*)sums, C, (double)M, scale, mean, rstd,
+                     batch_stats, dgamma, dbeta, coef);
   SC_LAUNCH_CHECK("bn_bwd_finish_kernel");
   const unsigned g2 = flat_grid(M * ((C + 3) / 4));
   if (dtype == 0)

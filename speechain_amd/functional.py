@@ -344,7 +344,9 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
     sink = GradSinks.take(params) if params else None
     dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    splitk = min(16, max(1, 512 // tiles), max(1, M // 256))
+    # (at most 16 slices for the transformer's products, M ~ 8000; up to 64 for the prenet's conv weight gradient, whose contraction
+    # runs over all B*T'*F' = 151 392 output positions while its output is as small as 64 x 576)
+    splitk = min(16 if M < 32768 else 64, max(1, 512 // tiles), max(1, M // 256))
     db = None
     if code == BF16 and splitk >= 2:
         if bias:
@@ -986,7 +988,7 @@ class _ConvFirst(torch.autograd.Function):
         moments = mean = rstd = None
         bn = gamma is not None
         if bn and training:
-            ws = torch.empty(lib.value("sc_conv1_moments_workspace", B, To, kh, kw), dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.value("sc_conv1_moments_workspace", *g6), dtype=torch.uint8, device=dev)
             moments = torch.empty(KK * KK + KK, dtype=torch.float64, device=dev)
             lib.call("sc_conv1_moments", _p(x), x.stride(0), x.stride(1), *g6, _p(moments), _p(ws), ws.numel(), stream())
             scale, shift, mean, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
@@ -1021,7 +1023,7 @@ class _ConvFirst(torch.autograd.Function):
         dw = _sink_or_new([pw_], (C, KK), dev)
         dgamma = _sink_or_new([pg], (C,), dev) if bn else None
         dbeta = _sink_or_new([pbe], (C,), dev) if bn else (_sink_or_new([pb], (C,), dev) if pb is not None else None)
-        ws = torch.empty(lib.value("sc_conv1_bwd_workspace", B, To, C, KK), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.value("sc_conv1_bwd_workspace", *g6, C), dtype=torch.uint8, device=dev)
         lib.call("sc_conv1_bwd", dcode(dy), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope), _p(dy),
                  _p(moments), _p(gamma.detach()) if bn else None, _p(mean), _p(rstd), 1 if batch_stats else 0, _p(dw), _p(dgamma), _p(dbeta),
                  _p(ws), ws.numel(), stream())

@@ -3,7 +3,7 @@
 SpeeChain's own ``ASREncoder`` / ``ARASRDecoder`` / ``ARASR`` (module/encoder/asr.py:103-131, module/decoder/ar_asr.py:49-78,
 model/ar_asr.py:386-388,453-458,550) are not part of the hot path and are not re-implemented; with
 ``speechain_amd.register.register()`` they run unmodified on top of these modules.  This class wires the same modules in the
-same order for parity tests, ``smoke()`` and ``bench.py``: [frontend -> SpecAugment -> prenet ->] encoder -> embedding ->
+same order for parity tests, ``smoke()`` and ``bench.py``: [frontend -> SpecAugment -> Conv2dPrenet ->] encoder -> embedding ->
 decoder -> token heads -> ``(1 - w) * CE + w * CTC``.
 """
 import torch
@@ -27,33 +27,6 @@ class Embed(torch.nn.Module):
 
     def forward(self, text):
         return self.embed(text)
-
-
-class Conv2dSubsample(torch.nn.Module):
-    """Stand-in for the recipe's Conv2dPrenet (module/prenet/conv2d.py:164-280: two Conv2d(k3, s2, no bias) + BatchNorm2d +
-    LeakyReLU as the transformer recipes configure it, then Linear) -- OUTSIDE the named hot path, so it is plain
-    torch/MIOpen here.  (B, T, F) -> (B, T', d).  NOTE conv_dims: both settings occur in the
-    reference's recipes for this transformer: (64, 64) in transformer-wide_ctc_perturb (and as the module default), (d_model,
-    d_model) = (512, 512) in transformer-large, where the prenet costs 29 ms of MIOpen time per 32-utterance step (DESIGN.md
-    section 6; bench.py --prenet-dims 512,512)."""
-
-    def __init__(self, feat_dim: int = 80, conv_dims=(64, 64), d_model: int = 512):
-        super().__init__()
-        layers, prev, f = [], 1, feat_dim
-        for c in conv_dims:
-            layers += [torch.nn.Conv2d(prev, c, 3, 2, bias=False), torch.nn.BatchNorm2d(c), torch.nn.LeakyReLU()]
-            prev, f = c, (f - 3) // 2 + 1
-        self.conv = torch.nn.Sequential(*layers)
-        self.linear = torch.nn.Linear(prev * f, d_model)
-        self.n_conv = len(conv_dims)
-
-    def forward(self, feat, feat_len):
-        x = self.conv(feat.unsqueeze(1))
-        B, C, T, Fd = x.shape
-        x = x.transpose(1, 2).contiguous().view(B, T, C * Fd)
-        for _ in range(self.n_conv):
-            feat_len = torch.div(feat_len - 3, 2, rounding_mode="floor") + 1
-        return self.linear(x), feat_len
 
 
 class ASRTransformer(torch.nn.Module):

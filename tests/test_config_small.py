@@ -32,11 +32,15 @@ def _batch():
     return wave, lens, text, text_len
 
 
+PRENET = dict(conv_dims=[32, 32], conv_kernel=3, conv_stride=2, conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=CFG["d_model"])
+
+
 def _model_and_prenet():
-    from speechain_amd.harness import ASRTransformer, Conv2dSubsample
+    from speechain_amd.harness import ASRTransformer
+    from speechain_amd.module.prenet.conv2d import Conv2dPrenet
 
     torch.manual_seed(5)
-    prenet = Conv2dSubsample(80, (32, 32), CFG["d_model"])
+    prenet = Conv2dPrenet(input_size=80, **PRENET)  # on the CPU it only holds the parameters: the oracle does the arithmetic
     model = ASRTransformer(**CFG, dropout=0.0, activation="GELU", posenc_maxlen=400, label_smoothing=0.2, ctc_weight=0.3)
     for m in (prenet, model):
         for p in m.parameters():
@@ -58,8 +62,10 @@ def _oracle_step(prenet, model, wave, lens, text, text_len, draws=None):
     if draws is None:
         draws = R.specaug_draw(flen, feat.size(0), 80, **SPECAUG)
     feat = R.specaug_apply(feat, flen, draws)
-    x, xlen = prenet(feat, flen)
+    PP = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in prenet.state_dict().items()}
+    x, xlen, _ = R.conv2d_prenet(feat, flen, PP, "", **PRENET, training=True)
     P = _oracle_params(model)
+    P.update({"prenet." + k: v for k, v in PP.items()})
     cfg = dict(enc_layers=CFG["enc_layers"], dec_layers=CFG["dec_layers"], num_heads=CFG["num_heads"], d_model=CFG["d_model"],
                activation="GELU", label_smoothing=0.2, ctc_weight=0.3)
     out = R.asr_forward_loss(x, xlen, text, text_len, P, cfg)
@@ -71,7 +77,7 @@ def test_transformer_small_plumbing_on_the_cpu_oracle():
     wave, lens, text, text_len = _batch()
     prenet, model = _model_and_prenet()
     torch.manual_seed(1)
-    out, P, (feat, flen, x, xlen, draws) = _oracle_step(prenet.train(), model, wave, lens, text, text_len)
+    out, P, (feat, flen, x, xlen, draws) = _oracle_step(prenet, model, wave, lens, text, text_len)
     want_flen = [int(n) // 160 + 1 for n in lens]  # centred STFT, hop 160 (speech2linear.py:201-212)
     want_xlen = [((n - 3) // 2 + 1 - 3) // 2 + 1 for n in want_flen]  # two k3 / s2 convolutions (prenet/conv2d.py:257-266)
     assert feat.shape == (4, want_flen[0], 80) and flen.tolist() == want_flen
@@ -81,10 +87,11 @@ def test_transformer_small_plumbing_on_the_cpu_oracle():
         assert torch.isfinite(out[k]) and float(out[k]) > 0
     grads = [v.grad for k, v in P.items() if v.requires_grad]
     assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads)
-    assert all(p.grad is not None for p in prenet.parameters())  # the gradient reaches the conv prenet through the encoder input
+    # the gradient reaches the conv prenet through the encoder input
+    assert all(v.grad is not None for k, v in P.items() if k.startswith("prenet.") and v.requires_grad)
     # reproducible: the same draws give the same loss
     prenet2, model2 = _model_and_prenet()
-    out2, _, _ = _oracle_step(prenet2.train(), model2, wave, lens, text, text_len, draws=draws)
+    out2, _, _ = _oracle_step(prenet2, model2, wave, lens, text, text_len, draws=draws)
     assert float(out2["loss"]) == float(out["loss"])
 
 
@@ -98,7 +105,6 @@ def test_transformer_small_hip_path_vs_oracle(mode):
 
     wave, lens, text, text_len = _batch()
     prenet, model = _model_and_prenet()
-    prenet.eval()  # BatchNorm with its (initial) running statistics: deterministic and identical on both sides
     torch.manual_seed(1)
     ref, P, (rfeat, rflen, rx, rxlen, draws) = _oracle_step(prenet, model, wave, lens, text, text_len)
     Fn.set_compute_dtype(mode)
@@ -111,10 +117,15 @@ def test_transformer_small_hip_path_vs_oracle(mode):
         feat = sa.apply(feat, {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in draws.items()})
         assert torch.equal(flen.cpu(), rflen)
         assert float((feat.cpu() - rfeat).abs().max()) < 2e-3  # log-mel 1e-3, normalised by a std of ~0.5-1
-        # named path on the oracle's prenet output (the prenet is outside the path and identical torch code on both sides)
-        gm = model.cuda().train()
-        out = gm(rx.cuda(), rxlen.cuda(), text.cuda(), text_len.cuda())
+        # Conv2dPrenet (row f2, training-mode BatchNorm) on the oracle's augmented features, then the named path on ITS output
         f32 = mode == torch.float32
+        gp = prenet.cuda().train()
+        x, xlen = gp(rfeat.cuda(), rflen.cuda())
+        assert torch.equal(xlen.cpu(), rxlen)
+        xe = float((x.float().cpu() - rx).norm() / rx.norm())
+        assert xe < (1e-5 if f32 else 2e-2), xe
+        gm = model.cuda().train()
+        out = gm(x, xlen, text.cuda(), text_len.cuda())
         lt = dict(atol=2e-4, rtol=1e-3) if f32 else dict(atol=0.1, rtol=2e-2)
         for k in ("ce", "ctc", "loss"):
             assert torch.allclose(out[k].detach().float().cpu(), ref[k].detach(), **lt), (k, float(out[k]), float(ref[k]))
@@ -131,6 +142,10 @@ def test_transformer_small_hip_path_vs_oracle(mode):
         for prm, key in pairs:
             g, r = prm.grad.detach().float().cpu(), P[key].grad
             assert torch.allclose(g, r, **gt), (key, float((g - r).abs().max()), float(r.abs().max()))
+        for name, prm in gp.named_parameters():  # the prenet's gradients came back through 12 encoder layers
+            g, r = prm.grad.detach().float().cpu(), P["prenet." + name].grad
+            e = float((g - r).norm() / (r.norm() + 1e-30))
+            assert e < (5e-4 if f32 else 0.2), (name, e)
     finally:
         Fn.set_compute_dtype(None)
         Fn.weights.invalidate()
