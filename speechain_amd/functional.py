@@ -333,6 +333,13 @@ class _Side:
             self.main.wait_stream(self.side)
 
 
+import os as _os
+# Workgroups a split-K weight gradient aims for.  Measured on the bench step (scripts/ab_wgrad.sh, two alternating rounds on one box,
+# 40 steps each): 128 -> 14.21 / 14.27 ms, 192 -> 13.69 / 13.83, 256 -> 13.46 / 13.55, 320 -> 13.55 / 13.56, 384 -> 13.74 / 13.65,
+# 512 -> 14.03 / 13.84, 768 -> 14.42 / 14.12: one workgroup per CU -- more slices only add partial slabs for the reduce kernel to stream.
+_WGRAD_WG_TARGET = int(_os.environ.get("SC_WGRAD_WG_TARGET", "256"))
+
+
 def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.Tensor] = (), bias: bool = False,
           bias_params: Sequence[torch.Tensor] = ()):
     """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K), written into the registered gradient slots of `params` when they
@@ -346,7 +353,7 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     # (at most 16 slices for the transformer's products, M ~ 8000; up to 64 for the prenet's conv weight gradient, whose contraction
     # runs over all B*T'*F' = 151 392 output positions while its output is as small as 64 x 576)
-    splitk = min(16 if M < 32768 else 64, max(1, 512 // tiles), max(1, M // 256))
+    splitk = min(16 if M < 32768 else 64, max(1, _WGRAD_WG_TARGET // tiles), max(1, M // 256))
     db = None
     if code == BF16 and splitk >= 2:
         if bias:
