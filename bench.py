@@ -166,6 +166,9 @@ class ASRTrainStepWorkload:
         self.g_body = self.g_tail = None
         self.loss = None
         self.use_graph = os.environ.get("BENCH_NO_GRAPH", "0") != "1"
+        # more than one rank: backward is captured in pieces and each piece's finished buckets are all-reduced under the next one
+        self.segmented = self.reducer.multi and os.environ.get("BENCH_NO_SEGMENTS", "0") != "1"
+        self.g_pieces, self.piece_buckets = [], []
 
     # ---- the two device-side halves of a step; eager or replayed from hipGraphs --------------------------------------
     def _body(self):
@@ -184,6 +187,53 @@ class ASRTrainStepWorkload:
         self.reducer.settle()
         return out["loss"].detach()
 
+    # ---- multi-rank: the same work in pieces, so that finished gradient buckets travel while the rest of backward runs ----------
+    def _piece_params(self):
+        """Parameters whose gradients each backward piece produces; the cut tensors are the encoder output, two encoder hidden states and
+        the encoder input (the prenet's output)."""
+        m = self.model
+        enc = m.encoder
+        late = [m.decoder, m.embed, m.postnet, m.ctc_layer]
+        groups = [[p for mod in late for p in mod.parameters()],
+                  [p for l in enc.trfm_layers[8:] for p in l.parameters()] + list(enc.layernorm.parameters()),
+                  [p for l in enc.trfm_layers[4:8] for p in l.parameters()],
+                  [p for l in enc.trfm_layers[:4] for p in l.parameters()] + list(enc.posenc.parameters()),
+                  list(self.prenet.parameters())]
+        assert sum(len(g) for g in groups) == len(self.params)
+        return [[p for p in g if p.requires_grad] for g in groups]
+
+    def _pieces(self):
+        """The device work of `_body` as five callables sharing state: forward + backward down to the encoder output, then backward
+        through encoder layers 11..8, 7..4, 3..0 and the prenet.  Each ends where `torch.autograd.backward(..., inputs=...)` is told to
+        stop; the gradient that crosses a cut is accumulated in the cut tensor's .grad and handed to the next piece."""
+        from speechain_amd import functional as Fn
+
+        st = {}
+        P = self._piece_params()
+
+        def first():
+            Fn.DropoutState.advance()
+            Fn.weights.refresh()
+            self.reducer.zero_grad()
+            x, xlen = self.prenet(self.feat, self.flen)
+            x = x.view_as(x)  # cut tensors must come from a metadata-only node (see TransformerEncoder.forward)
+            out = self.model(x, xlen, self.text, self.text_len)
+            hid = out["enc_hidden"]
+            st["cuts"] = [out["enc"], hid[7], hid[3], x]
+            st["loss"] = out["loss"].detach()
+            torch.autograd.backward([out["loss"]], inputs=P[0] + [st["cuts"][0]])
+
+        def middle(k):
+            def run():
+                cut = st["cuts"][k - 1]
+                nxt = [st["cuts"][k]] if k < len(st["cuts"]) else []
+                torch.autograd.backward([cut], grad_tensors=[cut.grad], inputs=P[k] + nxt)
+                if not nxt:
+                    self.reducer.settle()
+            return run
+
+        return [first] + [middle(k) for k in range(1, 5)], st
+
     def _tail(self):
         """global-norm clip at 5.0 (no host sync) -> fused Adam."""
         flats = [b["flat"] for b in self.reducer.buckets]
@@ -201,9 +251,26 @@ class ASRTrainStepWorkload:
         # rejects from any thread while a capture is open ("operation not permitted when stream is capturing").
         self.reducer.wait()
         torch.cuda.synchronize()
-        self.g_body = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
-            self.loss = self._body()
+        if self.segmented:
+            # one hipGraph per piece, all in one memory pool (activations saved by the first piece are consumed by the later ones); after
+            # each capture the reducer tells which buckets that piece completed -- at replay time their all-reduces are issued right
+            # after that piece, on the communication stream, while the next piece runs
+            pieces, st = self._pieces()
+            self.g_pieces, self.piece_buckets, taken, pool = [], [], set(), None
+            for run in pieces:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    run()
+                pool = g.pool()
+                self.g_pieces.append(g)
+                self.piece_buckets.append(self.reducer.completed_buckets(taken))
+            self.piece_buckets[-1] += [i for i in range(len(self.reducer.buckets)) if i not in taken]  # (buckets holding unused parameters)
+            self.loss = st["loss"]
+            self.g_body = self.g_pieces[0]
+        else:
+            self.g_body = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
+                self.loss = self._body()
         self.g_tail = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
             self._tail()
@@ -225,6 +292,14 @@ class ASRTrainStepWorkload:
         graph = self.use_graph and not instrument and self.nstep > 3
         if graph and self.g_body is None:
             self._capture()
+        if graph and self.segmented:
+            for g, ready in zip(self.g_pieces, self.piece_buckets):
+                g.replay()
+                for bi in ready:
+                    self.reducer.launch_bucket(bi)
+            self.reducer.wait()  # the optimizer's stream waits for the collectives; nothing is launched twice
+            self.g_tail.replay()
+            return self.loss
         if graph:
             self.g_body.replay()
             if self.reducer.multi:
@@ -462,8 +537,12 @@ def main():
             "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": SAMPLES,
                        "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
                                     f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
-                                    "buckets, issued between the backward hipGraph and the optimizer hipGraph (not overlapped with "
-                                    "backward in this graph-captured step); plus the two (80,)-vector all-gathers of the feature "
+                                    "buckets" + (" -- backward is replayed as five hipGraphs (cut at the encoder output, two encoder "
+                                    "hidden states and the encoder input) and the buckets each piece completes are reduced on a "
+                                    "communication stream while the next piece runs; the optimizer hipGraph waits for them"
+                                                 if getattr(wl, "segmented", False) else
+                                                 " (a single rank: no collective is issued; forward + backward is one hipGraph)")
+                                    + "; plus the two (80,)-vector all-gathers of the feature "
                                     "normalisation statistics in the eager part of the step, as in the reference")},
             "roofline": roof,
         }

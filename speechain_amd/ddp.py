@@ -139,6 +139,21 @@ class GradBucketReducer:
             self._launch(b)
         self.wait()
 
+    def completed_buckets(self, taken: set) -> List[int]:
+        """Indices of the buckets whose every gradient has been accumulated since ``zero_grad()`` and that are not in `taken` (which is
+        updated).  For a trainer that CAPTURES backward in several hipGraphs: called after each piece is captured (the hooks run at capture
+        time and count, but launch nothing), it tells which buckets that piece completes -- and hence which all-reduces may be issued
+        right after that piece's replay, overlapping the next one."""
+        out = [i for i, b in enumerate(self.buckets) if i not in taken and b["ready"] == len(b["params"])]
+        taken.update(out)
+        return out
+
+    def launch_bucket(self, index: int):
+        """Issues the all-reduce of one bucket now (behind an event on the current stream); ``wait()`` will not launch it again."""
+        b = self.buckets[index]
+        b["ready"] = -1
+        self._launch(b)
+
     def broadcast_parameters(self, src: int = 0):
         """One-off parameter (and nothing else) broadcast at start-up."""
         if not self.multi:

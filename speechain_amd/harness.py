@@ -48,7 +48,7 @@ class ASRTransformer(torch.nn.Module):
     def forward(self, feat, feat_len, text, text_len):
         """feat (B, T', d_model) encoder input; text (B, L) with <sos/eos> at both ends of every sentence."""
         enc_mask = make_mask_from_len(feat_len, max_len=feat.size(1))
-        enc, enc_mask, _, _ = self.encoder(feat, enc_mask)
+        enc, enc_mask, _, enc_hidden = self.encoder(feat, enc_mask)
         # the trailing <sos/eos> of every sentence becomes padding, then the last column is dropped (model/ar_asr.py:386-388)
         pos = torch.arange(text.size(1), device=text.device)[None, :]
         dec_in = text.masked_fill(pos == (text_len - 1)[:, None], 0)  # (no indexed assignment: that would sync the host)
@@ -60,4 +60,5 @@ class ASRTransformer(torch.nn.Module):
         ce = self.ce_loss(logits=logits, text=text, text_len=text_len)
         ctc = self.ctc_loss(ctc_logits, feat_len, text, text_len)
         loss = (1 - self.ctc_weight) * ce + self.ctc_weight * ctc
-        return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=loss)
+        # (enc_hidden: the per-layer encoder outputs, encoder.py:339-343 -- a trainer that cuts backward into pieces uses them as cut points)
+        return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=loss, enc_hidden=enc_hidden)

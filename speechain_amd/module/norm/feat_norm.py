@@ -59,24 +59,32 @@ def apply_stats(feat: torch.Tensor, mean: Optional[torch.Tensor], std: Optional[
 def ddp_batch_statistics(curr_means: Optional[torch.Tensor], curr_stds: Optional[torch.Tensor], batch_size: int, group=None):
     """Batch-level mean / std across all processes: sum of the per-utterance vectors of every rank divided by the total number of
     utterances (feat_norm.py:236-265 with gather_scalars :341-351 and gather_vectors :353-394).  Pure torch + torch.distributed
-    on the tensors' own device (RCCL on the GPU, gloo in the CPU test)."""
+    on the tensors' own device (RCCL on the GPU, gloo in the CPU test).
+
+    The reference gathers the batch sizes, the means and the stds in three collectives; here ONE all-gather carries
+    [batch size | sum of means | sum of stds] per rank (the sizes travel as float32, exact below 2^24): this sits on the host-bound
+    head of the training step (between the frontend and SpecAugment's host-side draws), where every collective costs its launch latency
+    in full.  The size is written by a device-side fill, not copied from the host (a pageable host-to-device copy waits for the stream)."""
     import torch.distributed as dist
 
     ref = curr_means if curr_means is not None else curr_stds
     world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=ref.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([batch_size], dtype=torch.int64, device=ref.device), group=group)
-    total = torch.cat(sizes).sum()
-
-    def reduce(v):
+    feats = ref.size(-1)
+    parts = [torch.full((1,), float(batch_size), dtype=torch.float32, device=ref.device)]
+    parts += [v.sum(dim=0).float() for v in (curr_means, curr_stds) if v is not None]
+    mine = torch.cat(parts)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    tot = torch.stack(gathered).sum(dim=0)
+    total = tot[0]
+    out, off = [], 1
+    for v in (curr_means, curr_stds):
         if v is None:
-            return None
-        mine = v.sum(dim=0)
-        parts = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        return torch.stack(parts).sum(dim=0) / total
-
-    return reduce(curr_means), reduce(curr_stds)
+            out.append(None)
+        else:
+            out.append((tot[off: off + feats] / total).to(v.dtype))
+            off += feats
+    return out[0], out[1]
 
 
 class FeatureNormalization(Module):

@@ -97,8 +97,12 @@ class TransformerEncoder(Module):
         attmat, hidden = [], []
         for layer in self.trfm_layers:
             src, _att = layer(src, pad_mask, _causal=self.uni_direction)
+            # A metadata-only autograd node (no kernel, nothing saved) between the layers: a trainer that runs backward in pieces
+            # (torch.autograd.backward(..., inputs=[hidden[k]])) needs its cut tensors to come from such a node -- autograd releases the
+            # saved tensors of a custom Function whose output is a capture point, and the next piece then cannot run it.
+            src = src.view_as(src)
             attmat.append(_att)
             hidden.append(src)
         if self.layernorm_first:
-            src = _ln(self.layernorm, src)
+            src = _ln(self.layernorm, src).view_as(src)  # (same: the encoder output is the natural first cut)
         return src, mask, attmat, hidden
