@@ -152,8 +152,14 @@ class ASRTrainStepWorkload:
         self.params = [p for m in (self.prenet, self.model) for p in m.parameters()]
         self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
-        self.lr = torch.tensor(2e-3, device=device)
-        self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)
+        self.lr = torch.tensor([2e-3], device=device)
+        # clip at 5.0 + Adam(0.9, 0.98, 1e-9) over the flat buckets in two launches (csrc/optim.hip); BENCH_TORCH_ADAM=1: stock torch ops
+        self.fused_opt = os.environ.get("BENCH_TORCH_ADAM", "0") != "1"
+        if self.fused_opt:
+            from speechain_amd.optim import FusedAdam
+            self.opt = FusedAdam(self.reducer, self.lr, betas=(0.9, 0.98), eps=1e-9, max_grad_norm=5.0)
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)
         torch.manual_seed(1234 + seed)
         self.wave, self.lens, _ = synth_batch(seed, device)
         self.text, self.text_len = synth_text(seed, device)
@@ -235,7 +241,10 @@ class ASRTrainStepWorkload:
         return [first] + [middle(k) for k in range(1, 5)], st
 
     def _tail(self):
-        """global-norm clip at 5.0 (no host sync) -> fused Adam."""
+        """global-norm clip at 5.0 (no host sync) -> Adam."""
+        if self.fused_opt:
+            self.opt.step()
+            return
         flats = [b["flat"] for b in self.reducer.buckets]
         norm = torch.sqrt(sum((f * f).sum() for f in flats))
         coef = torch.clamp(5.0 / (norm + 1e-6), max=1.0)

@@ -275,6 +275,20 @@ int sc_dropout(int dtype, const void* x, void* y, long long n, float scale, floa
 int sc_act_bwd(int dtype, const void* dy, const void* pre, void* dpre, long long n, int act, float drop_p,
                const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
+/* ---- optimizer tail: global-norm clipping + Adam over flat buffers -------------------------------------------------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step of the reference's training step (speechain/optim_sche/abs.py:232-253; Adam
+ * betas / eps from the recipes, e.g. recipes/asr/librispeech/train-clean-100/exp_cfg/100-bpe5k_transformer-large_lr2e-3.yaml:251-261).
+ * `nb` flat float32 buffers of `sizes[k]` elements each (the gradient buckets; parameters and both moments in buffers of the same
+ * layout); the pointer arrays are HOST arrays of device pointers, read at call time.
+ * state (device, 3 floats): [0] = ||g||^2 over all buffers, [1] = clip coefficient min(1, max_norm / (||g|| + 1e-6)) (1 when
+ * max_norm <= 0), [2] = step count -- sc_grad_sumsq writes [0], [1] and adds 1 to [2]; sc_adam_step reads [1], [2] and *lr:
+ *   g' = g * state[1];  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps). */
+long long sc_grad_sumsq_workspace(int nb, const long long* sizes);
+int sc_grad_sumsq(int nb, const float* const* grads, const long long* sizes, float max_norm, float* state, void* workspace,
+                  long long ws_bytes, hipStream_t stream);
+int sc_adam_step(int nb, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const long long* sizes, const float* lr, float beta1, float beta2, float eps, const float* state, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,28 @@ class GradBucketReducer:
             self._launch(b)
         self.wait()
 
+    def flatten_parameters(self):
+        """Moves every parameter's storage into a flat float32 buffer per bucket (same layout as the gradients) and returns the list of
+        those buffers: what a fused optimizer (``speechain_amd.optim.FusedAdam``) steps over.  Values are preserved; ``param.data``
+        becomes a view, so modules, ``state_dict`` and checkpoints see no difference."""
+        if getattr(self, "flat_params", None) is None:
+            self.flat_params = []
+            with torch.no_grad():
+                for b in self.buckets:
+                    flat = torch.empty_like(b["flat"])
+                    off = 0
+                    for p in b["params"]:
+                        v = flat[off: off + p.numel()].view_as(p)
+                        v.copy_(p.data)
+                        p.data = v
+                        off += p.numel()
+                    self.flat_params.append(flat)
+            if self.use_sinks:
+                from speechain_amd.functional import weights
+
+                weights.invalidate()  # cached compute-dtype copies are keyed by the old storage
+        return self.flat_params
+
     def completed_buckets(self, taken: set) -> List[int]:
         """Indices of the buckets whose every gradient has been accumulated since ``zero_grad()`` and that are not in `taken` (which is
         updated).  For a trainer that CAPTURES backward in several hipGraphs: called after each piece is captured (the hooks run at capture

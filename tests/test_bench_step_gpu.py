@@ -39,9 +39,10 @@ def _run(bench, use_graph: bool, steps: int, expect_pieces: int = 0):
         assert sum(len(bl) for bl in wl.piece_buckets[:-1]) >= len(wl.reducer.buckets) - 2, wl.piece_buckets
     # the clipped gradients of the last step, per parameter, read through the bucket slots (what the all-reduce ships and Adam uses)
     grads = {}
+    coef = float(wl.opt.clip_coef) if wl.fused_opt else 1.0  # (the fused optimizer applies the clip inside its update and leaves the slots unscaled)
     for b in wl.reducer.buckets:
         for prm, view in zip(b["params"], b["views"]):
-            grads[id(prm)] = view.detach().float().clone()
+            grads[id(prm)] = view.detach().float().clone() * coef
     named = {f"{tag}.{k}": grads[id(v)] for m, tag in ((wl.prenet, "prenet"), (wl.model, "model")) for k, v in m.named_parameters()}
     in_buckets = all(prm.grad is not None and prm.grad.data_ptr() == view.data_ptr()
                      for b in wl.reducer.buckets for prm, view in zip(b["params"], b["views"]))
