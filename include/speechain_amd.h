@@ -186,13 +186,17 @@ int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M
  * mean/rstd (R,) are saved for the backward pass (may be null).  Backward returns dx and the parameter gradients;
  * `workspace` needs sc_layernorm_bwd_workspace(R, D) bytes.  dres (nullable, (R, D) in `dtype`) is added to dx before the store: in a
  * pre-LN block the input of the LayerNorm also feeds the residual connection (encoder.py:115-141), and its second gradient is summed
- * here instead of in a separate elementwise launch. */
+ * here instead of in a separate elementwise launch.  `stages`: 3 = everything; 1 = dx and the per-workgroup partial sums only -- the
+ * parameter gradients of `n` such calls are then produced together by ONE launch of sc_layernorm_bwd_finish (host arrays of the
+ * calls' workspaces, R, D and outputs): nothing downstream reads them before the step ends. */
 int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                      long long R, int D, float eps, hipStream_t stream);
 long long sc_layernorm_bwd_workspace(long long R, int D);
 int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                      void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
-                     long long ws_bytes, hipStream_t stream);
+                     long long ws_bytes, int stages, hipStream_t stream);
+int sc_layernorm_bwd_finish(int n, const void* const* workspaces, const long long* R, const int* D, float* const* dgamma,
+                            float* const* dbeta, hipStream_t stream);
 
 /* out[n] = sum_r x[r][n] (bias gradients); deterministic two-stage reduction. */
 long long sc_colsum_workspace(long long R, int N);

@@ -6,6 +6,7 @@
 //   column sums                  -- bias gradients of every Linear
 // Activations are f32 or bf16 (template T); statistics, gammas, losses and reductions are always f32.
 #include "sc_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -304,6 +305,47 @@ __global__ __launch_bounds__(1024) void reduce_parts_kernel(const float* part, i
   }
 }
 
+// reduce_parts_kernel for a batch of independent (part, P, D, out0, out1) problems with nout = 2: blockIdx.z selects the problem
+constexpr int LN_BATCH = 64;
+struct LnFinishBatch {
+  const float* part[LN_BATCH];
+  float* out0[LN_BATCH];
+  float* out1[LN_BATCH];
+  int P[LN_BATCH];
+  int D[LN_BATCH];
+};
+
+__global__ __launch_bounds__(1024) void reduce_parts_batched_kernel(LnFinishBatch b) {
+  __shared__ float red[64][17];
+  const int z = blockIdx.z;
+  const float* part = b.part[z];
+  const int P = b.P[z], D = b.D[z];
+  const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + c;
+  const int j = blockIdx.y;
+  float s = 0.f;
+  if (k < D) {
+    for (int p0 = pl; p0 < P; p0 += 64 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int pp = p0 + 64 * u;
+        v[u] = pp < P ? part[((long long)pp * 2 + j) * D + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && k < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) t += red[i][c];
+    (j == 0 ? b.out0[z] : b.out1[z])[k] = t;
+  }
+}
+
 // column sums of an (R, N) matrix with row stride ld: part[blockIdx.y][n]; 256 threads = 64 columns x 4 row-lanes
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* x, long long R, int N, long long ld, int rows_per_block, float* part) {
@@ -543,8 +585,9 @@ SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
 
 SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                             void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
-                            long long ws_bytes, hipStream_t stream) {
+                            long long ws_bytes, int stages, hipStream_t stream) {
   SC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "sc_layernorm_bwd: null pointer");
+  SC_CHECK_ARG(stages == 1 || stages == 3, "sc_layernorm_bwd: stages is 1 (dx + partial sums; finish with sc_layernorm_bwd_finish) or 3 (everything)");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
   SC_CHECK_ARG(ws_bytes >= sc_layernorm_bwd_workspace(R, D), "sc_layernorm_bwd: workspace too small");
   long long blocks = (R + 7) / 8;
@@ -565,8 +608,40 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
                   (float*)workspace, R, D, rpb, dres);
   }
   SC_LAUNCH_CHECK("layernorm_bwd_kernel");
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(1024), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
-  SC_LAUNCH_CHECK("reduce_parts_kernel");
+  if (stages & 2) {
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(sc_cdiv(D, 16), 2), dim3(1024), 0, stream, (const float*)workspace, (int)blocks, 2, D, dgamma, dbeta);
+    SC_LAUNCH_CHECK("reduce_parts_kernel");
+  }
+  return SC_OK;
+}
+
+// Second stage of up to LN_BATCH LayerNorm backward calls in ONE launch (grid.z = call): in a training step the 44 parameter-gradient
+// reductions are not needed before the step ends, and as separate launches each costs its run time plus a dependency gap on the stream.
+SC_API int sc_layernorm_bwd_finish(int n, const void* const* workspaces, const long long* R, const int* D, float* const* dgamma,
+                                   float* const* dbeta, hipStream_t stream) {
+  SC_CHECK_ARG(workspaces && R && D && dgamma && dbeta, "sc_layernorm_bwd_finish: null pointer");
+  SC_CHECK_ARG(n >= 1, "sc_layernorm_bwd_finish: n=%d", n);
+  for (int i0 = 0; i0 < n; i0 += LN_BATCH) {
+    LnFinishBatch b{};
+    const int m = std::min(LN_BATCH, n - i0);
+    int dmax = 0;
+    for (int i = 0; i < m; ++i) {
+      const int k = i0 + i;
+      SC_CHECK_ARG(workspaces[k] && dgamma[k] && dbeta[k] && R[k] >= 1 && D[k] >= 1, "sc_layernorm_bwd_finish: bad entry %d", k);
+      long long blocks = (R[k] + 7) / 8;  // (the partition sc_layernorm_bwd uses)
+      if (blocks > 1024) blocks = 1024;
+      const int rpb = (int)((R[k] + blocks - 1) / blocks);
+      blocks = (R[k] + rpb - 1) / rpb;
+      b.part[i] = (const float*)workspaces[k];
+      b.out0[i] = dgamma[k];
+      b.out1[i] = dbeta[k];
+      b.P[i] = (int)blocks;
+      b.D[i] = D[k];
+      dmax = std::max(dmax, D[k]);
+    }
+    hipLaunchKernelGGL(reduce_parts_batched_kernel, dim3(sc_cdiv(dmax, 16), 2, m), dim3(1024), 0, stream, b);
+    SC_LAUNCH_CHECK("reduce_parts_batched_kernel");
+  }
   return SC_OK;
 }
 

@@ -119,6 +119,10 @@ class GradBucketReducer:
             # event.  The caller reduces every bucket eagerly after the replay instead (reduce_all_now).
             return
         if self.cuda:
+            if self.use_sinks:  # LayerNorm parameter gradients queued for the end of backward belong to the slots too
+                from speechain_amd.functional import _LnFinish
+
+                _LnFinish.flush()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):

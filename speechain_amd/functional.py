@@ -277,6 +277,7 @@ class GradSinks:
     @classmethod
     def begin_step(cls):
         cls.step += 1
+        _LnFinish.reset()  # (entries of a backward call that raised must not survive into the next step)
 
     @classmethod
     def take(cls, params: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -586,6 +587,48 @@ def ffn(x, w1, b1, w2, b2, activation: str, p_hidden: float = 0.0, p_res: float 
 # LayerNorm
 # ---------------------------------------------------------------------------------------------------------------------
 
+class _LnFinish:
+    """Pending second stages of LayerNorm backward calls (dgamma / dbeta from the partial sums) whose outputs are gradient-bucket slots:
+    nothing reads those before the step ends, so they are produced together by ONE launch when the running backward call finishes
+    (autograd engine callback) -- 43 launches and as many dependency gaps fewer per training step.  Entries are raw addresses; only the
+    workspaces are kept alive (a lingering reference to the gradient views would make autograd's accumulation clone them right away,
+    before they are written)."""
+
+    pending = []   # (workspace address, R, D, dgamma address, dbeta address)
+    keep = []      # the workspace tensors
+    armed = False
+    enabled = _os.environ.get("SC_LN_BATCH_FINISH", "1") == "1"  # (A/B knob)
+
+    @classmethod
+    def add(cls, ws: torch.Tensor, R: int, D: int, dg: torch.Tensor, db: torch.Tensor):
+        cls.pending.append((ws.data_ptr(), R, D, dg.data_ptr(), db.data_ptr()))
+        cls.keep.append(ws)
+        if not cls.armed:
+            cls.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+
+    @classmethod
+    def reset(cls):
+        cls.pending.clear()
+        cls.keep.clear()
+        cls.armed = False
+
+    @classmethod
+    def flush(cls):
+        """Launches the pending reductions on the current stream (also called by GradBucketReducer before it ships a bucket)."""
+        cls.armed = False
+        if not cls.pending:
+            return
+        import ctypes
+
+        n = len(cls.pending)
+        col = lambda i, ct: (ct * n)(*[e[i] for e in cls.pending])
+        lib.call("sc_layernorm_bwd_finish", n, col(0, ctypes.c_void_p), col(1, ctypes.c_longlong), col(2, ctypes.c_int),
+                 col(3, ctypes.c_void_p), col(4, ctypes.c_void_p), stream())
+        cls.pending.clear()
+        cls.keep.clear()
+
+
 class _LayerNorm(torch.autograd.Function):
     """LayerNorm over the last dim.  With `with_residual` the input is also returned unchanged as a second output for the residual
     connection of a pre-LN block to use: the block input then reaches autograd through this function only, backward receives both of
@@ -632,8 +675,11 @@ class _LayerNorm(torch.autograd.Function):
         dg = sg if sg is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         db = sb if sb is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         ws = torch.empty(lib.value("sc_layernorm_bwd_workspace", R, D), dtype=torch.uint8, device=x2.device)
+        batched = _LnFinish.enabled and sg is not None and sb is not None  # both outputs are bucket slots: see _LnFinish
         lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
-                 _p(dr2), _p(ws), ws.numel(), stream())
+                 _p(dr2), _p(ws), ws.numel(), 1 if batched else 3, stream())
+        if batched:
+            _LnFinish.add(ws, R, D, dg, db)
         return dx.reshape(ctx.xshape), dg, db, None, None
 
 
