@@ -32,8 +32,10 @@ BATCH, SAMPLES = 32, 160000
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # (100 timed steps by default, ~1.3 s: ONE of them runs eagerly with HIP events around every GEMM launch -- the roofline must be
+    #  measured inside the timed region -- and takes ~26 ms instead of ~12.7; over 20 steps that alone adds 0.65 ms to the average)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
     ap.add_argument("--prenet-dims", default="64,64",
                     help="conv channels of the Conv2d prenet in front of the encoder (SURVEY row f2; HIP path, FLOPs outside the named-path count). "

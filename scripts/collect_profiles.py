@@ -21,7 +21,7 @@ def main():
     shutil.copy(G + "prof/frontend_bench.json", P + "r01_frontend_bench_under_rocprof.json")
     shutil.copy(G + "prof/train_bench.json", P + "r01_train_step_bench_under_rocprof.json")
     for src, dst in (("bench_default.json", "r01_train_step_bench_default.json"), ("bench_frontend_default.json", "r01_frontend_bench_default.json"),
-                     ("bench_p512.json", "r01_train_step_bench_prenet512.json"), ("bench_40.json", "r01_train_step_bench_40steps.json")):
+                     ("bench_p512.json", "r01_train_step_bench_prenet512.json"), ("bench_40.json", "r01_train_step_bench_20steps.json")):
         if os.path.exists(G + src):
             shutil.copy(G + src, P + dst)
     out, rows_out = {}, []
@@ -46,7 +46,7 @@ def main():
         w = csv.DictWriter(f, fieldnames=list(rows_out[0].keys()))
         w.writeheader()
         w.writerows(rows_out)
-    for tag in ("r01_train_step_bench_default", "r01_train_step_bench_40steps", "r01_train_step_bench_prenet512", "r01_train_step_bench_under_rocprof"):
+    for tag in ("r01_train_step_bench_default", "r01_train_step_bench_20steps", "r01_train_step_bench_prenet512", "r01_train_step_bench_under_rocprof"):
         if os.path.exists(P + tag + ".json"):
             d = json.load(open(P + tag + ".json"))
             r = d["roofline"]
@@ -62,7 +62,7 @@ def main():
     print(f"--- train-step kernel stats per step ({steps} steps traced)")
     for r in csv.DictReader(open(P + "r01_train_step_kernel_stats.csv")):
         if any(k in r["Name"] for k in ("nt_dma_kernel", "gemm_bf16_kernel", "splitk_reduce", "attn_", "layernorm", "ctc_", "featnorm", "frontend_pfa",
-                                        "specaug_kernel", "reduce_parts", "cast_weights", "multi_tensor_apply", "row_lse", "ce_", "conv1_", "im2col", "col2im", "bn_",
+                                        "specaug_kernel", "reduce_parts", "cast_weights", "multi_tensor_apply", "row_lse", "ce_", "conv1_", "im2col", "col2im", "bn_", "adam_step", "grad_sumsq",
                                         "sum_partials")):
             print(f"  {float(r['AverageNs']) / 1e3:8.1f} us avg {int(r['Calls']) / steps:6.1f} calls/step {float(r['TotalDurationNs']) / 1e6 / steps:6.3f} ms/step  {r['Name'][:80]}")
     print("--- frontend run")

@@ -354,7 +354,8 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     # (at most 16 slices for the transformer's products, M ~ 8000; up to 64 for the prenet's conv weight gradient, whose contraction
     # runs over all B*T'*F' = 151 392 output positions while its output is as small as 64 x 576)
-    splitk = min(16 if M < 32768 else 64, max(1, _WGRAD_WG_TARGET // tiles), max(1, M // 256))
+    # (rounded, not floored: the vocabulary heads' 5000 x 512 gradients are 160 tiles -- one slice would send them to the generic kernel)
+    splitk = min(16 if M < 32768 else 64, max(1, (_WGRAD_WG_TARGET + tiles // 2) // tiles), max(1, M // 256))
     db = None
     if code == BF16 and splitk >= 2:
         if bias:
