@@ -369,7 +369,8 @@ class ASRTrainStepWorkload:
         dom_id, (dt, df, dc) = max(single.items(), key=lambda kv: kv[1][0]) if single else (0, (0.0, 0.0, 0))
         achieved = df / (dt * 1e-3) / 1e12 if dt > 0 else 0.0
         return {"bound": "mfma", "kernel": lib.load().sc_gemm_kernel_name(dom_id).decode(), "achieved": round(achieved, 2),
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5),
+                "traffic": pmc_traffic(lib.load().sc_gemm_kernel_name(dom_id).decode()),
                 "launches_timed": dc, "avg_launch_ms": round(dt / max(dc, 1), 5), "kernel_flops_timed": df,
                 "all_gemm_launches": {"achieved": round(agg, 2), "frac": round(agg / MFMA_BF16_PEAK_TFLOPS, 5), "launches_timed": n,
                                       "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops},
@@ -379,17 +380,20 @@ class ASRTrainStepWorkload:
                         "replay hipGraphs); `kernel` is the single GEMM kernel with the largest summed time in that step, achieved = its "
                         "2*M*N*K*batch flops / its event time; the split-K entries of by_kernel time two launches (product + "
                         "splitk_reduce_kernel) in one interval and are therefore not eligible as `kernel`; traffic: "
-                        "no PMC pass is committed for the GEMM kernels (null)"}
+                        "HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_train_step_pmc_traffic.json: "
+                        "FETCH_SIZE x 2 + WRITE_SIZE over eager steps, averaged over the mix of shapes the kernel serves)"}
 
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_frontend_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                return json.load(f)[kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):

@@ -46,6 +46,26 @@ def main():
         w = csv.DictWriter(f, fieldnames=list(rows_out[0].keys()))
         w.writeheader()
         w.writerows(rows_out)
+    # train step: the same two passes over a few eager steps (scripts/pmc_train.sh), averaged per kernel
+    if glob.glob(G + "prof/train_fetch/*/*counter_collection.csv"):
+        keys = ("gemm_bf16_nt_dma_kernel<2, 2, 2>", "gemm_bf16_nt_dma_kernel<2, 4, 4>", "gemm_bf16_nt_dma_kernel<2, 2, 1>", "gemm_bf16_kernel<true, true>",
+                "attn_fwd_stream_kernel", "attn_bwd_kernel", "adam_step_kernel", "grad_sumsq_kernel", "cast_weights_kernel")
+        tr = {}
+        for kind, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(newest(G + f"prof/train_{kind}/*/*counter_collection.csv"))):
+                for key in keys:
+                    if key in r["Kernel_Name"]:
+                        agg[key].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                tr.setdefault(k, {})[cn + "_kB_per_launch"] = round(sum(v) / len(v), 1)
+                tr[k]["launches_counted"] = len(v)
+        for d in tr.values():
+            d["hbm_bytes_per_launch"] = int(round((2 * d["FETCH_SIZE_kB_per_launch"] + d["WRITE_SIZE_kB_per_launch"]) * 1000))
+        tr["_note"] = ("separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `BENCH_NO_GRAPH=1 python bench.py --steps 3 --warmup 2` (eager steps), averaged over "
+                       "every launch of the kernel in the run -- i.e. over the MIX of shapes a kernel serves in the step; FETCH_SIZE doubled per the gfx950 "
+                       "correction (MI355X_MICROARCH.md, HBM / rocprofv3); unit 1000 B")
+        json.dump(tr, open(P + "r01_train_step_pmc_traffic.json", "w"), indent=1)
     for tag in ("r01_train_step_bench_default", "r01_train_step_bench_20steps", "r01_train_step_bench_prenet512", "r01_train_step_bench_under_rocprof"):
         if os.path.exists(P + tag + ".json"):
             d = json.load(open(P + tag + ".json"))
