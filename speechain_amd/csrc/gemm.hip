@@ -19,6 +19,7 @@
 // are staged with 16-byte loads/stores into rows padded to 80 B (bf16) / 68 B (f32) so the MFMA fragment reads
 // are bank-conflict free; row-contiguous operands are transposed on their way into LDS.
 #include "sc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -1219,6 +1220,7 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_tn_dma_splitk_kernel + splitk_reduce_kernel",
     "gemm_bf16_kernel (split-K, other layout) + splitk_reduce_kernel",
     "gemm_bf16_nt_dma_kernel<2, 2, 1>",
+    "gemm_bf16_nt_dma_kernel<2, 1, 1>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 SC_API const char* sc_gemm_kernel_name(int id) {
@@ -1272,6 +1274,12 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
       if (big >= 160 && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
+      // Very few tiles (the decoder's M = 2016, N = 512 products: 64 tiles of 128 x 128, 128 of 64 x 128): 64 x 64 tiles, two waves each,
+      // put a workgroup on every CU.  Step-level A/B (40 steps, alternating): 12.35 / 12.36 / 12.55 ms with them vs 12.60 / 12.61 / 12.69
+      // without; thresholds of 80, 128 and 192 tiles measure the same (12.53 .. 12.64 on another box), 256 hurts (12.99).
+      // SC_GEMM_T64=<max tiles> overrides (0 switches the variant off).
+      static const long long t64max = [] { const char* e = getenv("SC_GEMM_T64"); return e ? atoll(e) : 80LL; }();
+      if (t128 <= t64max) { g_last_gemm_kernel = 12; return launch_dma<2, 1, 1>(a, nb, stream); }
       if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
       g_last_gemm_kernel = 1;
       return launch_dma<2, 2, 2>(a, nb, stream);

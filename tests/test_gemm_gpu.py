@@ -33,6 +33,21 @@ def test_layouts_and_ragged_shapes(dtype, ta, tb, M, N, K):
     assert torch.allclose(C.double(), ref, **_tol(dtype, K)), float((C.double() - ref).abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,res", [(2016, 512, 512, True), (2016, 512, 2048, True), (1000, 512, 512, False), (2016, 320, 1536, False)])
+def test_few_tile_products_on_64x64_tiles(M, N, K, res):
+    """The decoder-sized products (at most 80 tiles of 128 x 128) go to the two-wave 64 x 64 LDS-DMA tiles: plain and with the
+    bias + residual epilogue, ragged in M and N."""
+    A, B = _mk((M, K), torch.bfloat16, 11), _mk((N, K), torch.bfloat16, 12)
+    bias = _mk((N,), torch.float32, 13)
+    R = _mk((M, N), torch.bfloat16, 14)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    Fn.gemm(Fn.BF16, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, bias=bias, aux=Fn._p(R) if res else None, ldaux=N, aux_mode=1 if res else 0)
+    from speechain_amd._lib import lib
+    assert lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode() == "gemm_bf16_nt_dma_kernel<2, 1, 1>"
+    ref = A.double() @ B.double().t() + bias.double() + (R.double() if res else 0)
+    assert torch.allclose(C.double(), ref, **_tol(torch.bfloat16, K)), float((C.double() - ref).abs().max())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batched_head_strides(dtype):
     """Q K^T on head-interleaved (B, T, 3d) buffers, as the attention core issues it."""
