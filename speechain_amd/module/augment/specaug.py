@@ -50,9 +50,8 @@ class SpecAugment(Module):
 
     def draw(self, feat_len: torch.Tensor, batch_size: int, feat_dim: int, device) -> Dict:
         """The random integers of one call, drawn exactly as specaug.py:87-191 does (host logic, no kernel)."""
-        tmax, tmin = int(feat_len.max().item()), int(feat_len.min().item())
-        d = dict(time_maxlen=tmax, time_minlen=tmin, warp_center=None, warp_pos=None, freq_len=None, freq_pos=None,
-                 time_len=None, time_pos=None)
+        tmin = int(feat_len.min().item())  # (specaug.py:87 -- one of the three device-to-host reads the draw order forces)
+        d = dict(time_minlen=tmin, warp_center=None, warp_pos=None, freq_len=None, freq_pos=None, time_len=None, time_pos=None)
         W = self.time_warp_window
         if self.time_warp and tmin > 2 * W + 1:
             d["warp_center"] = torch.randint(low=W + 1, high=tmin - W, size=(1,))[0].item()
