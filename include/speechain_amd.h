@@ -258,6 +258,11 @@ int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long*
 
 /* dtype casts (0 = f32, 1 = bf16) and the transposed cast out[c][r] = in[r][c] of an (R, C) f32 matrix. */
 int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
+/* dW (V, D) f32 of out = table[ids] from dy (N, D; row stride ld): autograd of the token embedding (speechain/module/prenet/embed.py:55-66).
+ * Deterministic, no atomics (the first position holding an id sums all of that id's rows in position order); the row of padding_idx
+ * (nn.Embedding's) stays zero; pass a negative padding_idx for none.  ids in [0, V). */
+int sc_embedding_bwd(int dtype, const long long* ids, const void* dy, long long ld, int N, int D, int V, long long padding_idx, float* dw,
+                     hipStream_t stream);
 int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, long long ld_out, hipStream_t stream);
 
 /* Batched refresh of compute-dtype weight copies in ONE launch.  `desc` is a device array of n_desc records

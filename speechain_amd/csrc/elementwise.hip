@@ -3,6 +3,7 @@
 //   positional-encoding add with scale / learnable alpha / dropout -- speechain/module/transformer/pos_enc.py:168-182
 //   dropout apply (forward of residual dropout's backward: dy * keep / (1 - p)) -- encoder.py:119,134; decoder.py:126,150,166
 #include "sc_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -132,7 +133,65 @@ inline unsigned grid_for(long long n) {
   return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
+// Gradient of an embedding lookup, deterministic and without atomics: one wave per token position.  The wave of position i owns row
+// ids[i] of the table gradient iff no earlier position holds the same id; the owner then adds the rows dy[j] of ALL positions j >= i with
+// that id in position order (matches found 64 at a time by ballot) and writes the table row once.  Rows nobody owns are zeroed by
+// embedding_zero_kernel beforehand; the padding id receives no gradient (nn.Embedding(padding_idx=...)).
+__global__ __launch_bounds__(256) void embedding_zero_kernel(float* dw, long long n4) {
+  float4* p = reinterpret_cast<float4*>(dw);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void embedding_bwd_kernel(const long long* ids, const T* dy, long long ld, int N, int D, long long padding_idx,
+                                                           float* dw) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const long long my = ids[i];
+  if (my == padding_idx) return;
+  for (int base = 0; base < i; base += 64) {
+    const int j = base + lane;
+    if (__ballot(j < i && ids[j] == my)) return;  // an earlier position owns this row
+  }
+  for (int c0 = 0; c0 < D; c0 += 64 * 4) {  // 4 columns per lane and pass
+    const int c = c0 + lane * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = i; base < N; base += 64) {
+      const int j = base + lane;
+      unsigned long long mask = __ballot(j < N && ids[j] == my);
+      while (mask) {
+        const int row = base + __builtin_ctzll(mask);
+        mask &= mask - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < D) acc[e] += Io<T>::ld(dy, (long long)row * ld + c + e);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < D) dw[my * D + c + e] = acc[e];
+  }
+}
+
 }  // namespace
+
+// dW (V, D) f32 of out = table[ids] from dy (N, D) (row stride ld) -- the autograd of the token embedding in front of the decoder
+// (speechain/module/prenet/embed.py:55-66).  ids must lie in [0, V).
+SC_API int sc_embedding_bwd(int dtype, const long long* ids, const void* dy, long long ld, int N, int D, int V, long long padding_idx, float* dw,
+                            hipStream_t stream) {
+  SC_CHECK_ARG(ids && dy && dw, "sc_embedding_bwd: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_embedding_bwd: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(N >= 1 && D >= 1 && V >= 1 && ld >= D, "sc_embedding_bwd: bad sizes N=%d D=%d V=%d ld=%lld", N, D, V, ld);
+  SC_CHECK_ARG((long long)V * D % 4 == 0 && (uintptr_t)dw % 16 == 0, "sc_embedding_bwd: the table gradient must be 16-byte aligned with V*D a multiple of 4");
+  const long long n4 = (long long)V * D / 4;
+  hipLaunchKernelGGL(embedding_zero_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, stream, dw, n4);
+  SC_LAUNCH_CHECK("embedding_zero_kernel");
+  if (dtype == 0)
+    hipLaunchKernelGGL(embedding_bwd_kernel<float>, dim3(N), dim3(64), 0, stream, ids, (const float*)dy, ld, N, D, padding_idx, dw);
+  else
+    hipLaunchKernelGGL(embedding_bwd_kernel<unsigned short>, dim3(N), dim3(64), 0, stream, ids, (const unsigned short*)dy, ld, N, D, padding_idx, dw);
+  SC_LAUNCH_CHECK("embedding_bwd_kernel");
+  return SC_OK;
+}
 
 // dtype codes: 0 = f32, 1 = bf16
 SC_API int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream) {

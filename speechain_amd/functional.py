@@ -1209,3 +1209,37 @@ def conv_block(x, conv: torch.nn.Conv2d, bn: Optional[torch.nn.BatchNorm2d], act
     if first:
         return _ConvFirst.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps, compute_dtype())
     return _ConvNext.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Token embedding:  out = table[ids]   (gather left to torch; the table gradient by csrc/elementwise.hip, deterministic)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, padding_idx):
+        require_gpu(table, "the token embedding")
+        ctx.save_for_backward(ids)
+        ctx.table = table
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        return torch.nn.functional.embedding(ids, table.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        table = ctx.table
+        V, D = table.shape
+        dy2 = dy.reshape(-1, D)
+        if dy2.stride(1) != 1:
+            dy2 = dy2.contiguous()
+        flat = ids.reshape(-1).to(torch.int64)
+        flat = flat if flat.is_contiguous() else flat.contiguous()
+        sink = GradSinks.take([table])
+        dw = sink.view(V, D) if sink is not None else torch.empty(V, D, dtype=torch.float32, device=table.device)
+        lib.call("sc_embedding_bwd", dcode(dy2), _p(flat), _p(dy2), dy2.stride(0), flat.numel(), D, V, ctx.padding_idx, _p(dw), stream())
+        return dw, None, None
+
+
+def embedding(table: torch.Tensor, ids: torch.Tensor, padding_idx: Optional[int] = None) -> torch.Tensor:
+    """nn.Embedding lookup whose table gradient is produced without atomics (and straight into its gradient-bucket slot)."""
+    return _Embedding.apply(table, ids, padding_idx)

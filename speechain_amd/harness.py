@@ -18,15 +18,15 @@ from speechain_amd.utilbox.train_util import make_mask_from_len
 
 
 class Embed(torch.nn.Module):
-    """Token embedding with the reference's parameter name ``embed.weight`` (module/prenet/embed.py:14-66); a gather,
-    left to torch (outside the named path)."""
+    """Token embedding with the reference's parameter name ``embed.weight`` (module/prenet/embed.py:14-66).  The lookup is a torch gather;
+    the table gradient comes from ``sc_embedding_bwd`` (deterministic, written straight into its gradient-bucket slot)."""
 
     def __init__(self, vocab_size: int, dim: int, padding_idx: int = 0):
         super().__init__()
-        self.embed = torch.nn.Embedding(vocab_size, dim, padding_idx=padding_idx)
+        self.embed = torch.nn.Embedding(vocab_size, dim, padding_idx=padding_idx)  # parameter holder (and its initialisation)
 
     def forward(self, text):
-        return self.embed(text)
+        return Fn.embedding(self.embed.weight, text, self.embed.padding_idx)
 
 
 class ASRTransformer(torch.nn.Module):

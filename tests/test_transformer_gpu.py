@@ -482,3 +482,27 @@ def test_streaming_attention_forward_through_the_c_abi(Tq, Tk, causal):
     assert torch.equal(torch.isfinite(got), fin)
     assert float((got[fin] - ref_lse[fin]).abs().max()) < 2e-3 if bool(fin.any()) else True
     assert float(out[2].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_embedding_table_gradient_vs_torch(dtype):
+    """sc_embedding_bwd (one wave per position, the first holder of an id sums its rows in position order) against nn.Embedding's
+    autograd: repeated ids, the padding id, ids that never occur, D not a multiple of the 256-column pass."""
+    from speechain_amd import functional as Fn
+    gen = torch.Generator().manual_seed(5)
+    for V, D, B, L in ((5000, 512, 32, 63), (37, 100, 3, 70), (9, 8, 2, 5)):
+        table = torch.nn.Parameter(torch.randn(V, D, generator=gen).cuda())
+        ids = torch.randint(0, V, (B, L), generator=gen)
+        ids[0, :4] = 0           # padding id
+        ids[1, :] = ids[1, 0]    # one id many times
+        ids = ids.cuda()
+        w = torch.randn(B, L, D, generator=gen).cuda().to(dtype)
+        out = Fn.embedding(table, ids, 0)
+        assert torch.equal(out, torch.nn.functional.embedding(ids, table.detach()))
+        (out.to(dtype) * w).sum().backward()
+        got, table.grad = table.grad.clone(), None
+        ref = torch.nn.functional.embedding(ids, table, padding_idx=0)
+        (ref.to(dtype) * w).sum().backward()
+        assert float(got[0].abs().max()) == 0.0  # the padding row
+        scale = float(table.grad.abs().max())
+        assert torch.allclose(got, table.grad, atol=(1e-5 if dtype == torch.float32 else 2e-2) * scale, rtol=1e-5), float((got - table.grad).abs().max())
