@@ -33,69 +33,103 @@ __device__ __forceinline__ float cubic_outer(float x, float A) { return ((A * x 
 
 constexpr int kMaxMasks = 16;
 
+// One workgroup = kRowsPerBlock consecutive frames of one utterance.  The mask ranges of the utterance are staged in LDS once and the
+// frequency mask is expanded to one flag per column once (the first version re-derived both per element from global memory in 8032
+// workgroups of ~320 elements each: 29 us for 20 MB, all of it block prologue latency); a thread then owns 4 consecutive columns
+// (16-byte loads / stores when F % 4 == 0) and walks the rows.  Per-element arithmetic is unchanged.
+constexpr int kRowsPerBlock = 32;
+constexpr int kMaxF = 1024;
+
 __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
+  __shared__ long long tps[kMaxMasks * 64], tln[kMaxMasks * 64];
+  __shared__ int fm[kMaxF];
   const int b = blockIdx.y;
-  const int rows_per_block = blockDim.y;
-  const int t = blockIdx.x * rows_per_block + threadIdx.y;
-  if (t >= p.T) return;
-  const float fillv = p.fill ? *p.fill : 0.f;
-
-  // time mask for this row (uniform over the row's threads)
-  bool tmask = false;
-  for (int i = 0; i < p.nt; ++i) {
-    const long long ps = p.time_pos[b * p.nt + i], ln = p.time_len[b * p.nt + i];
-    tmask |= (ps <= t) && (t < ps + ln);
-  }
-
-  // warp source rows and taps
-  int idx[4];
-  float w[4];
-  bool warp = p.warp_center >= 0 && t < p.tmin;
-  if (warp) {
-    int base, in_len, dst;
-    float scale;
-    if (t < p.warp_pos) { base = 0; in_len = p.warp_center; dst = t; scale = p.scale_l; }
-    else { base = p.warp_center; in_len = p.tmin - p.warp_center; dst = t - p.warp_pos; scale = p.scale_r; }
-    float real = scale * (float)dst;
-    asm volatile("" : "+v"(real));  // aten rounds the product before taking floor / fraction: keep hipcc from
-                                    // contracting it into fma(scale, dst, -floor) (HIP's __fmul_rn does not)
-    int i0 = (int)floorf(real);
-    if (i0 > in_len - 1) i0 = in_len - 1;
-    float lam = real - (float)i0;
-    lam = fminf(fmaxf(lam, 0.f), 1.f);
-    const float A = -0.75f;
-    w[0] = cubic_outer(lam + 1.f, A);
-    w[1] = cubic_inner(lam, A);
-    w[2] = cubic_inner(1.f - lam, A);
-    w[3] = cubic_outer(2.f - lam, A);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int q = i0 - 1 + j;
-      q = q < 0 ? 0 : (q > in_len - 1 ? in_len - 1 : q);
-      idx[j] = base + q;
-    }
-  }
-
-  const float* src = p.in + (long long)b * p.T * p.F;
-  float* dst_row = p.out + ((long long)b * p.T + t) * p.F;
-  for (int f = threadIdx.x; f < p.F; f += blockDim.x) {
-    bool masked = tmask;
+  const int row0 = blockIdx.x * kRowsPerBlock;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < p.nt; i += 256) { tps[i] = p.time_pos[b * p.nt + i]; tln[i] = p.time_len[b * p.nt + i]; }
+  for (int f = tid; f < p.F; f += 256) {
+    bool m = false;
     for (int i = 0; i < p.nf; ++i) {
       const long long ps = p.freq_pos[b * p.nf + i], ln = p.freq_len[b * p.nf + i];
-      masked |= (ps <= f) && (f < ps + ln);
+      m |= (ps <= f) && (f < ps + ln);
     }
-    float v;
-    if (masked) {
-      v = fillv;
-    } else if (warp) {
-      v = src[(long long)idx[0] * p.F + f] * w[0];
-      v += src[(long long)idx[1] * p.F + f] * w[1];
-      v += src[(long long)idx[2] * p.F + f] * w[2];
-      v += src[(long long)idx[3] * p.F + f] * w[3];
-    } else {
-      v = src[(long long)t * p.F + f];
+    fm[f] = m ? 1 : 0;
+  }
+  __syncthreads();
+  const float fillv = p.fill ? *p.fill : 0.f;
+  const int FQ = (p.F + 3) >> 2;                 // column quads per row
+  const int lanes = max(1, 256 / FQ);            // rows in flight
+  const int q = tid % FQ, rl = tid / FQ;
+  const bool vec = (p.F & 3) == 0 && (((uintptr_t)p.in | (uintptr_t)p.out) & 15) == 0;
+  const float* src = p.in + (long long)b * p.T * p.F;
+  for (int qq = q; qq < FQ && rl < lanes; qq += 256) {  // (FQ > 256 only for F > 1024, which the host refuses)
+    const int f0 = qq * 4, nc = min(4, p.F - f0);
+    for (int t = row0 + rl; t < min(row0 + kRowsPerBlock, p.T); t += lanes) {
+      bool tmask = false;
+      for (int i = 0; i < p.nt; ++i) tmask |= (tps[i] <= t) && (t < tps[i] + tln[i]);
+      int idx[4];
+      float w[4];
+      const bool warp = p.warp_center >= 0 && t < p.tmin;
+      if (warp) {
+        int base, in_len, dst;
+        float scale;
+        if (t < p.warp_pos) { base = 0; in_len = p.warp_center; dst = t; scale = p.scale_l; }
+        else { base = p.warp_center; in_len = p.tmin - p.warp_center; dst = t - p.warp_pos; scale = p.scale_r; }
+        float real = scale * (float)dst;
+        asm volatile("" : "+v"(real));  // aten rounds the product before taking floor / fraction: keep hipcc from
+                                        // contracting it into fma(scale, dst, -floor) (HIP's __fmul_rn does not)
+        int i0 = (int)floorf(real);
+        if (i0 > in_len - 1) i0 = in_len - 1;
+        float lam = real - (float)i0;
+        lam = fminf(fmaxf(lam, 0.f), 1.f);
+        const float A = -0.75f;
+        w[0] = cubic_outer(lam + 1.f, A);
+        w[1] = cubic_inner(lam, A);
+        w[2] = cubic_inner(1.f - lam, A);
+        w[3] = cubic_outer(2.f - lam, A);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int qi = i0 - 1 + j;
+          qi = qi < 0 ? 0 : (qi > in_len - 1 ? in_len - 1 : qi);
+          idx[j] = base + qi;
+        }
+      }
+      float v[4];
+      if (warp) {
+        float r[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* sp = src + (long long)idx[j] * p.F + f0;
+          if (vec) { const float4 x = *reinterpret_cast<const float4*>(sp); r[j][0] = x.x; r[j][1] = x.y; r[j][2] = x.z; r[j][3] = x.w; }
+          else { for (int e = 0; e < 4; ++e) r[j][e] = e < nc ? sp[e] : 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = r[0][e] * w[0];
+          a += r[1][e] * w[1];
+          a += r[2][e] * w[2];
+          a += r[3][e] * w[3];
+          v[e] = a;
+        }
+      } else {
+        const float* sp = src + (long long)t * p.F + f0;
+        if (vec) { const float4 x = *reinterpret_cast<const float4*>(sp); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+        else { for (int e = 0; e < 4; ++e) v[e] = e < nc ? sp[e] : 0.f; }
+      }
+      // (a select, not `if (tmask || (e < nc && fm[..])) v[e] = fillv`: hipcc 7.2 compiled that short-circuit form into code that
+      //  computed the column flag and then ignored it -- frequency masks silently had no effect)
+      int fl4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fl4[e] = fm[min(f0 + e, p.F - 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool hit = tmask | ((e < nc) & (fl4[e] != 0));
+        v[e] = hit ? fillv : v[e];
+      }
+      float* dp = p.out + ((long long)b * p.T + t) * p.F + f0;
+      if (vec) *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
+      else { for (int e = 0; e < nc; ++e) dp[e] = v[e]; }
     }
-    dst_row[f] = v;
   }
 }
 
@@ -141,10 +175,9 @@ SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int 
   a.freq_len = freq_len; a.freq_pos = freq_pos; a.nf = nf;
   a.time_len = time_len; a.time_pos = time_pos; a.nt = nt;
   a.fill = fill;
-  const int bx = F >= 64 ? 64 : 32;
-  dim3 block(bx, 256 / bx);
-  dim3 grid(sc_cdiv(T, block.y), B);
-  hipLaunchKernelGGL(specaug_kernel, grid, block, 0, stream, a);
+  SC_CHECK_ARG(F <= kMaxF, "sc_specaug_fwd: at most %d feature columns", kMaxF);
+  dim3 grid(sc_cdiv(T, kRowsPerBlock), B);
+  hipLaunchKernelGGL(specaug_kernel, grid, dim3(256), 0, stream, a);
   SC_LAUNCH_CHECK("specaug_kernel");
   return SC_OK;
 }
