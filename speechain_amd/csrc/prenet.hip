@@ -119,18 +119,23 @@ constexpr int MAX_TAPS = 15;  // KH*KW of the first block (9 in every recipe): K
 
 __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long long sb, long long st, Geo g, Tiling tl, double* partial) {
   extern __shared__ float rows[];  // [(R-1)*SH + KH][Fi + 2*PW] (zero borders)
+  __shared__ double half[128];     // the second row-lane's sums (entries < 128 have two lanes)
   const int KK = g.KH * g.KW, NE = KK * KK + KK;
   const int W = g.Fi + 2 * g.PW;
-  const int q = threadIdx.x;
+  // entry q < NE of the moment set; with NE <= 128 two threads share an entry and split a tile's output rows (even / odd)
+  const int split = NE <= 128 ? 2 : 1;
+  const int q = threadIdx.x % 128, sub = threadIdx.x / 128;
+  const bool live = split == 2 ? q < NE : (int)threadIdx.x < NE;
+  const int e = split == 2 ? q : (int)threadIdx.x;
   int oi = 0, oj = 0;  // LDS offsets of the two taps of this entry, relative to the patch origin
   bool pair = false;
-  if (q < KK * KK) {
-    const int i = q / KK, j = q % KK;
+  if (e < KK * KK) {
+    const int i = e / KK, j = e % KK;
     oi = (i / g.KW) * W + (i % g.KW);
     oj = (j / g.KW) * W + (j % g.KW);
     pair = true;
-  } else if (q < NE) {
-    const int j = q - KK * KK;
+  } else if (e < NE) {
+    const int j = e - KK * KK;
     oi = (j / g.KW) * W + (j % g.KW);
   }
   double acc = 0.0;
@@ -146,8 +151,8 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long
       rows[i] = (t >= 0 && t < g.Ti && f >= 0 && f < g.Fi) ? x[(long long)b * sb + (long long)t * st + f] : 0.f;
     }
     __syncthreads();
-    if (q < NE)
-      for (int ro = 0; ro < nr; ++ro) {
+    if (live)
+      for (int ro = (split == 2 ? sub : 0); ro < nr; ro += split) {
         const float* base = rows + ro * g.SH * W;
         for (int fo = 0; fo < g.Fo; ++fo) {  // float64 throughout: the variance is a difference of these moments
           const double a = (double)base[fo * g.SW + oi];
@@ -155,7 +160,13 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long
         }
       }
   }
-  if (q < NE) partial[(long long)blockIdx.x * NE + q] = acc;
+  if (split == 2) {  // fixed order: lane 0 + lane 1
+    if (sub == 1) half[q] = acc;
+    __syncthreads();
+    if (sub == 0 && live) partial[(long long)blockIdx.x * NE + e] = acc + half[q];
+  } else if (live) {
+    partial[(long long)blockIdx.x * NE + e] = acc;
+  }
 }
 
 // BatchNorm2d coefficients of channel c from the moments (training): scale = gamma * rstd, shift = beta - mean * scale; the
@@ -405,6 +416,46 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* a, Geo g, int C, T
 }
 
 // da[b][t][f][c] = sum over the taps (kh, kw) that reach (t, f): dcol[(b, (t+PH-kh)/SH, (f+PW-kw)/SW)][(kh, kw, c)]
+// bf16 with C % 8 == 0: 8 channels (16 bytes) per thread
+__global__ __launch_bounds__(256) void col2im_bf16x8_kernel(const unsigned short* dcol, Geo g, int C, unsigned short* da) {
+  const int CV = C >> 3;
+  const long long KKC = (long long)g.KH * g.KW * C;
+  const long long total = (long long)g.B * g.Ti * g.Fi * CV;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long long r = i / CV;
+    const int f = (int)(r % g.Fi);
+    r /= g.Fi;
+    const int t = (int)(r % g.Ti), b = (int)(r / g.Ti);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < g.KH; ++kh) {
+      const int tt = t + g.PH - kh;
+      if (tt < 0 || tt % g.SH) continue;
+      const int to = tt / g.SH;
+      if (to >= g.To) continue;
+      for (int kw = 0; kw < g.KW; ++kw) {
+        const int ff = f + g.PW - kw;
+        if (ff < 0 || ff % g.SW) continue;
+        const int fo = ff / g.SW;
+        if (fo >= g.Fo) continue;
+        const uint4 u = *reinterpret_cast<const uint4*>(dcol + (((long long)b * g.To + to) * g.Fo + fo) * KKC + (long long)(kh * g.KW + kw) * C + cv * 8);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += __uint_as_float(w[j] << 16);
+          acc[2 * j + 1] += __uint_as_float(w[j] & 0xFFFF0000u);
+        }
+      }
+    }
+    uint4 o;
+    o.x = (unsigned)sc_f32_to_bf16(acc[0]) | ((unsigned)sc_f32_to_bf16(acc[1]) << 16);
+    o.y = (unsigned)sc_f32_to_bf16(acc[2]) | ((unsigned)sc_f32_to_bf16(acc[3]) << 16);
+    o.z = (unsigned)sc_f32_to_bf16(acc[4]) | ((unsigned)sc_f32_to_bf16(acc[5]) << 16);
+    o.w = (unsigned)sc_f32_to_bf16(acc[6]) | ((unsigned)sc_f32_to_bf16(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(da + (((long long)b * g.Ti + t) * g.Fi + f) * C + cv * 8) = o;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, Geo g, int C, T* da) {
   const int CV = (C + 3) / 4;
@@ -764,6 +815,9 @@ SC_API int sc_col2im(int dtype, const void* dcol, int B, int Ti, int Fi, int C, 
   const long long items = (long long)B * Ti * Fi * ((C + 3) / 4);
   if (dtype == 0)
     hipLaunchKernelGGL(col2im_kernel<float>, dim3(flat_grid(items)), dim3(256), 0, stream, (const float*)dcol, g, C, (float*)da);
+  else if (C % 8 == 0)
+    hipLaunchKernelGGL(col2im_bf16x8_kernel, dim3(flat_grid((long long)B * Ti * Fi * (C / 8))), dim3(256), 0, stream, (const unsigned short*)dcol, g, C,
+                       (unsigned short*)da);
   else
     hipLaunchKernelGGL(col2im_kernel<unsigned short>, dim3(flat_grid(items)), dim3(256), 0, stream, (const unsigned short*)dcol, g, C,
                        (unsigned short*)da);
