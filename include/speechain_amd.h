@@ -160,7 +160,9 @@ int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, i
  *   aux_mode 2: v *= act'(aux[m][n])  else  v = act(v)   (act: 0 none, 1 ReLU, 2 exact GELU);
  *   dropout(drop_p) with the stateless generator keyed (*seed, offset + linear index of (z,m,n)); `seed` points to a
  *   device cell so that a captured hipGraph draws fresh masks on every replay once the host bumps the cell;
- *   aux_mode 1: v += aux[m][n];  store as `dtype`, or as float32 when out_f32 (optionally accumulating). */
+ *   aux_mode 1: v += aux[m][n];  aux_mode 3: v *= aux[m][n];  store as `dtype`, or as float32 when out_f32 (optionally accumulating).
+ * act | 0x100: pre_out receives act'(pre) * (dropped ? 0 : 1 / (1 - drop_p)) instead of the pre-activation -- exactly the factor the
+ * data-gradient product of the same layer multiplies by (aux_mode 3), so that launch neither re-evaluates act' nor the dropout mask. */
 int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void* C, int M, int N, int K, long long lda,
             long long ldb, long long ldc, int nb1, int nb2, long long sA1, long long sA2, long long sB1, long long sB2,
             long long sC1, long long sC2, float alpha, const float* bias, int act, void* pre_out, const void* aux,

@@ -24,7 +24,8 @@
 namespace {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
-enum { AUX_NONE = 0, AUX_ADD = 1, AUX_ACT_GRAD = 2 };
+enum { AUX_NONE = 0, AUX_ADD = 1, AUX_ACT_GRAD = 2, AUX_MUL = 3 };
+constexpr int ACT_PRE_GRAD = 0x100;  // flag bit of the `act` argument: pre_out receives act'(pre) * dropout factor instead of pre
 
 struct GemmArgs {
   const void* A;
@@ -37,6 +38,7 @@ struct GemmArgs {
   float alpha;
   const float* bias;
   int act;
+  int pre_grad;        // pre_out <- act'(v) * (dropped ? 0 : keep) (what a later data-gradient product multiplies by: AUX_MUL) instead of v
   void* pre_out;
   const void* aux;
   long long ldaux;
@@ -76,6 +78,7 @@ __device__ __forceinline__ float epilogue_elem(const GemmArgs& p, float v, float
   }
   v = dropped ? 0.f : v * keep;
   if (p.aux_mode == AUX_ADD) v += aux;
+  if (p.aux_mode == AUX_MUL) v *= aux;
   return v;
 }
 
@@ -132,6 +135,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const float* st
         dropped = ((h >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr;
       }
       v[j] = epilogue_elem(p, v[j], bias, has_aux ? aux[j] : 0.f, dropped, keep);
+      if (p.pre_grad) {
+        const float x = pre[j];
+        const float gprime = p.act == ACT_RELU ? (x > 0.f ? 1.f : 0.f) : (p.act == ACT_GELU ? sc_gelu_grad(x) : 1.f);
+        pre[j] = dropped ? 0.f : gprime * keep;
+      }
     }
     if (p.out_f32) {
       float* c = (float*)p.C + ci;
@@ -240,7 +248,7 @@ __device__ __forceinline__ void epilogue_tile_fast(const GemmArgs& p, const floa
 // Fused epilogues with the feature set fixed at compile time (the fully run-time `epilogue_tile` stays as the fallback):
 //   v = alpha*acc + bias;  [PRE: pre_out <- v];  ACTG ? v *= act'(aux) : v = act(v);  dropout (run-time p, hoisted);
 //   [ADD: v += aux];  store in the compute dtype.   ACT: 0 none, 1 ReLU, 2 GELU.
-template <typename T, bool BIAS, int ACT, bool ACTG, bool ADD, bool PRE>
+template <typename T, bool BIAS, int ACT, bool ACTG, bool ADD, bool PRE, bool PREG = false>
 __device__ __forceinline__ void epilogue_tile_fused(const GemmArgs& p, const float* stage, long long zoffC, int z, int mbase,
                                                     int nbase, int lane) {
   constexpr bool kBf16 = sizeof(T) == 2;
@@ -292,7 +300,16 @@ __device__ __forceinline__ void epilogue_tile_fused(const GemmArgs& p, const flo
       if (ACTG) {
         if (ACT == ACT_RELU) v[j] = aux[j] > 0.f ? v[j] : 0.f;
         else if (ACT == ACT_GELU) v[j] *= sc_gelu_grad_t<kBf16>(aux[j]);
+        else v[j] *= aux[j];  // AUX_MUL: the factor was prepared by the forward product (PREG)
+      } else if (PREG && ACT == ACT_GELU) {
+        // gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x): one erf serves both
+        const float x = v[j];
+        const float e = kBf16 ? sc_erf_fast(x * 0.70710678118654752f) : sc_erf(x * 0.70710678118654752f);
+        const float Phi = 0.5f * (1.f + e);
+        v[j] = x * Phi;
+        pre[j] = fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), Phi);
       } else {
+        if (PREG) pre[j] = (ACT == ACT_RELU) ? (v[j] > 0.f ? 1.f : 0.f) : 1.f;
         if (ACT == ACT_RELU) v[j] = fmaxf(v[j], 0.f);
         else if (ACT == ACT_GELU) v[j] = sc_gelu_t<kBf16>(v[j]);
       }
@@ -304,7 +321,9 @@ __device__ __forceinline__ void epilogue_tile_fused(const GemmArgs& p, const flo
       for (int j = 0; j < 8; ++j) {
         const unsigned long long idx = idx0 + j;
         if (j == 0 || (idx & 1) == 0) hsh = sc_rand_pair(seed, idx >> 1);
-        v[j] = (((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr) ? 0.f : v[j] * keep;
+        const bool dropped = ((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr;
+        v[j] = dropped ? 0.f : v[j] * keep;
+        if (PREG) pre[j] = dropped ? 0.f : pre[j] * keep;
       }
     }
     if (ADD) {
@@ -395,10 +414,16 @@ __device__ __forceinline__ void epilogue_wave_fused(const GemmArgs& p, float* st
                                                     int mrow0, int ncol0, int lane) {
 #define SC_RUN(...) run_epilogue<MI>(stage, acc, lane, [&](int i) { __VA_ARGS__(p, stage, zoffC, z, mrow0 + i * 32, ncol0, lane); })
   if (!p.out_f32 && p.bias) {
-    if (p.aux_mode == AUX_NONE && p.pre_out && p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_GELU, false, false, true>); return; }
-    if (p.aux_mode == AUX_NONE && p.pre_out && p.act == ACT_RELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_RELU, false, false, true>); return; }
+    if (p.aux_mode == AUX_NONE && p.pre_out && p.pre_grad && p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_GELU, false, false, true, true>); return; }
+    if (p.aux_mode == AUX_NONE && p.pre_out && p.pre_grad && p.act == ACT_RELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_RELU, false, false, true, true>); return; }
+    if (p.aux_mode == AUX_NONE && p.pre_out && !p.pre_grad && p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_GELU, false, false, true>); return; }
+    if (p.aux_mode == AUX_NONE && p.pre_out && !p.pre_grad && p.act == ACT_RELU) { SC_RUN(epilogue_tile_fused<T, true, ACT_RELU, false, false, true>); return; }
     if (p.aux_mode == AUX_ADD && !p.pre_out && p.act == ACT_NONE) { SC_RUN(epilogue_tile_fused<T, true, ACT_NONE, false, true, false>); return; }
     if (p.aux_mode == AUX_NONE && !p.pre_out && p.act == ACT_NONE && p.drop_p > 0.f) { SC_RUN(epilogue_tile_fused<T, true, ACT_NONE, false, false, false>); return; }
+  }
+  if (!p.out_f32 && !p.bias && p.aux_mode == AUX_MUL && !p.pre_out && p.act == ACT_NONE && p.drop_p == 0.f) {
+    SC_RUN(epilogue_tile_fused<T, false, ACT_NONE, true, false, false>);
+    return;
   }
   if (!p.out_f32 && !p.bias && p.aux_mode == AUX_ACT_GRAD && !p.pre_out) {
     if (p.act == ACT_GELU) { SC_RUN(epilogue_tile_fused<T, false, ACT_GELU, true, false, false>); return; }
@@ -1238,14 +1263,16 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && nb1 >= 1 && nb2 >= 1, "sc_gemm: bad sizes M=%d N=%d K=%d nb=%dx%d", M, N, K, nb1, nb2);
   SC_CHECK_ARG((long long)nb1 * nb2 <= 65535, "sc_gemm: batch %lld too large", (long long)nb1 * nb2);
   SC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? N : K) && ldc >= N, "sc_gemm: leading dimension too small");
-  SC_CHECK_ARG(aux_mode == AUX_NONE || aux, "sc_gemm: aux_mode %d without aux", aux_mode);
+  SC_CHECK_ARG(aux_mode >= AUX_NONE && aux_mode <= AUX_MUL && (aux_mode == AUX_NONE || aux), "sc_gemm: aux_mode %d (0..3) without aux or out of range", aux_mode);
+  SC_CHECK_ARG((act & 0xFF) <= ACT_GELU && (act & ~(0xFF | ACT_PRE_GRAD)) == 0, "sc_gemm: bad act code %d", act);
+  SC_CHECK_ARG(!(act & ACT_PRE_GRAD) || pre_out, "sc_gemm: the pre-gradient flag needs pre_out");
   SC_CHECK_ARG(!accumulate || out_f32, "sc_gemm: accumulate needs an f32 output");
   SC_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "sc_gemm: dropout p=%f", drop_p);
   SC_CHECK_ARG(drop_p == 0.f || seed, "sc_gemm: dropout needs a seed cell");
   GemmArgs a{};
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.nb2 = nb2; a.sA1 = sA1; a.sA2 = sA2; a.sB1 = sB1; a.sB2 = sB2; a.sC1 = sC1; a.sC2 = sC2;
-  a.alpha = alpha; a.bias = bias; a.act = act; a.pre_out = pre_out; a.aux = aux; a.ldaux = ldaux; a.aux_mode = aux_mode;
+  a.alpha = alpha; a.bias = bias; a.act = act & 0xFF; a.pre_grad = (act & ACT_PRE_GRAD) ? 1 : 0; a.pre_out = pre_out; a.aux = aux; a.ldaux = ldaux; a.aux_mode = aux_mode;
   a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p); a.seed = seed; a.offset = offset; a.out_f32 = out_f32; a.accumulate = accumulate;
   const long long esz = dtype == 0 ? 4 : 2;
   auto vec_ok = [&](const void* ptr, long long ld, long long s1, long long s2) {

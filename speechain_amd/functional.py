@@ -519,6 +519,9 @@ def linear_act(x, w, b, activation: str, drop_p: float = 0.0):
 # Position-wise feed-forward:  y = dropout_res( dropout_h(act(x W1^T + b1)) W2^T + b2 ) [+ residual]
 # ---------------------------------------------------------------------------------------------------------------------
 
+_FFN_PREGRAD = _os.environ.get("SC_FFN_PREGRAD", "1") == "1"
+
+
 class _FFN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, w1, b1, w2, b2, act, p_h, p_res):
@@ -533,8 +536,9 @@ class _FFN(torch.autograd.Function):
         h_pre = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
         h = torch.empty(M, Fd, dtype=x2.dtype, device=x2.device)
         s1, o1 = DropoutState.next(M * Fd, x2.device) if p_h > 0 else (0, 0)
-        gemm(code, _p(x2), _p(W1), _p(h), M, Fd, K, K, K, Fd, bias=b1.detach() if b1 is not None else None, act=act,
-             pre_out=_p(h_pre), drop=(p_h, s1, o1))
+        # (act | 0x100: the second output is act'(pre) * dropout factor, the multiplier of this layer's data gradient -- see backward)
+        gemm(code, _p(x2), _p(W1), _p(h), M, Fd, K, K, K, Fd, bias=b1.detach() if b1 is not None else None,
+             act=(act | 0x100) if _FFN_PREGRAD else act, pre_out=_p(h_pre), drop=(p_h, s1, o1))
         y = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
         s2, o2 = DropoutState.next(M * K, x2.device) if p_res > 0 else (0, 0)
         res2 = None
@@ -565,9 +569,13 @@ class _FFN(torch.autograd.Function):
         with side:
             dW2, db2 = wgrad(code, dz, h, [w2], bias=True, bias_params=ctx.bias_params[1]) if has_b2 \
                 else (wgrad(code, dz, h, [w2]), None)
-        # dpre = (dz W2) * act'(h_pre) * keepmask_h / (1 - p_h): fused into the dgrad epilogue
-        dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), act=act, aux=_p(h_pre), ldaux=Fd,
-                     aux_mode=2, drop=(p_h, s1, o1))
+        # dpre = (dz W2) * [act'(pre) * keepmask_h / (1 - p_h)]: the bracket was stored by the forward product (h_pre), so the dgrad
+        # epilogue is one multiply (it used to re-evaluate erf / exp and the dropout hash for every element)
+        if _FFN_PREGRAD:
+            dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), aux=_p(h_pre), ldaux=Fd, aux_mode=3)
+        else:  # (A/B knob SC_FFN_PREGRAD=0: h_pre holds the pre-activation, act' and the mask are re-evaluated here)
+            dpre = dgrad(code, dz, [w2], torch.empty(M, Fd, dtype=x2.dtype, device=x2.device), act=act, aux=_p(h_pre), ldaux=Fd,
+                         aux_mode=2, drop=(p_h, s1, o1))
         with side:
             dW1, db1 = wgrad(code, dpre, x2, [w1], bias=True, bias_params=ctx.bias_params[0]) if has_b1 \
                 else (wgrad(code, dpre, x2, [w1]), None)

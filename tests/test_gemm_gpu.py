@@ -178,3 +178,42 @@ def test_tn_split_k_dma_kernel_through_the_c_abi(monkeypatch, T, N, K, splitk):
     rb = dz.double().sum(0)
     bound = dz.double().abs().sum(0) * T * 2.0 ** -23 + 1e-6
     assert bool(((db.double() - rb).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("act", [1, 2], ids=["relu", "gelu"])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_pre_gradient_output_and_multiply_mode(dtype, act, p):
+    """act | 0x100: the second output is act'(pre) * dropout factor (with the SAME mask as the main output); aux_mode 3 multiplies a
+    product by such a tensor -- the pair the feed-forward layer uses so that its data gradient needs no erf / exp / mask hash."""
+    M, N, K = 300, 264, 96  # ragged: partial tiles on both sides
+    A, B = (_mk((M, K), torch.float32, 21) * 0.1).to(dtype), _mk((N, K), dtype, 22)  # pre-activations of order one (a saturated GELU is 0 too)
+    bias = _mk((N,), torch.float32, 23)
+    h = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    g = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    seed, off = Fn.DropoutState.next(M * N, A.device) if p > 0 else (0, 0)
+    Fn.gemm(Fn.dcode(A), Fn._p(A), Fn._p(B), Fn._p(h), M, N, K, K, K, N, bias=bias, act=act | 0x100, pre_out=Fn._p(g), drop=(p, seed, off))
+    pre = A.double() @ B.double().t() + bias.double()
+    fact = torch.nn.functional.relu(pre) if act == 1 else torch.nn.functional.gelu(pre)
+    gprime = (pre > 0).double() if act == 1 else (0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5)
+    keep = 1.0 / (1.0 - p)
+    if p > 0:  # the same elements are dropped in both outputs
+        live = (fact.abs() > 1e-2).to(h.device)  # where the activation itself is clearly non-zero, a zero output means "dropped"
+        dropped = (h == 0) & live
+        assert torch.equal(dropped, (g == 0) & live)
+        frac = float(dropped.float().sum() / live.float().sum())
+        assert abs(frac - p) < 0.02, frac
+        kept = ~(h == 0)
+    else:
+        kept = torch.ones_like(h, dtype=torch.bool)
+    t = dict(atol=2e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=6e-2, rtol=2e-2)
+    if act == 1:  # at ReLU's kink a rounding of `pre` decides the gate: compare away from it
+        kept = kept & (pre.abs() > 1e-3).to(kept.device)
+    assert torch.allclose(h.double()[kept], (fact.to(h.device) * keep)[kept], **t)
+    assert torch.allclose(g.double()[kept], (gprime.to(h.device) * keep)[kept], **t)
+    # aux_mode 3: C = (A2 B2^T) * g
+    A2, B2 = _mk((M, K), dtype, 24), _mk((N, K), dtype, 25)
+    C = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    Fn.gemm(Fn.dcode(A2), Fn._p(A2), Fn._p(B2), Fn._p(C), M, N, K, K, K, N, aux=Fn._p(g), ldaux=N, aux_mode=3)
+    ref = (A2.double() @ B2.double().t()) * g.double()
+    assert torch.allclose(C.double(), ref, **_tol(dtype, K)), float((C.double() - ref).abs().max())
