@@ -705,6 +705,16 @@ def layer_norm_with_residual(x, gamma, beta, eps: float):
 # Scaled dot-product attention core on head-interleaved buffers
 # ---------------------------------------------------------------------------------------------------------------------
 
+def _mask_bytes(mask: torch.Tensor) -> torch.Tensor:
+    """The attention mask as contiguous bytes.  A bool tensor already IS one byte per element holding 0 / 1: it is reinterpreted, not
+    converted (a `.to(torch.uint8)` here cost one copy kernel per attention call, 24 per training step)."""
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        mask = mask.to(torch.uint8)
+    return mask if mask.is_contiguous() else mask.contiguous()
+
+
 class _AttnCore(torch.autograd.Function):
     """q_buf (B, Tq, nq*d) and kv_buf (B, Tk, nkv*d) hold projections side by side along the last dim; q/k/v are the
     d-wide column blocks iq / ik / iv of those buffers (for self-attention q_buf IS kv_buf).  Heads are the dh-wide
@@ -730,8 +740,7 @@ class _AttnCore(torch.autograd.Function):
              sC=(H * Tq * ld, Tq * ld), alpha=scale)
         m8 = mb = mq = None
         if mask is not None:
-            m8 = mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask
-            m8 = m8.contiguous()
+            m8 = _mask_bytes(mask)
             mb = m8.stride(0)
             mq = m8.stride(1) if m8.size(1) > 1 else 0
         Pd = None
@@ -814,7 +823,7 @@ class _AttnFused(torch.autograd.Function):
         m8 = None
         mb = mq = 0
         if mask is not None:
-            m8 = (mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask).contiguous()
+            m8 = _mask_bytes(mask)
             mb, mq = m8.stride(0), (m8.stride(1) if m8.size(1) > 1 else 0)
         ld = _up(Tk, 8)
         seed, off = DropoutState.next(B * H * Tq * ld, dev) if drop_p > 0 else (0, 0)
