@@ -376,8 +376,8 @@ class ASRTrainStepWorkload:
                                       "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops},
                 "by_kernel": by_kernel,
                 "step_named_path": None,  # filled by main(): SURVEY 8d's 2.54 TFLOP of the named path / the measured step time
-                "note": "one timed step runs eagerly with HIP events around every sc_gemm/sc_gemm_splitk launch (the other steps "
-                        "replay hipGraphs); `kernel` is the single GEMM kernel with the largest summed time in that step, achieved = its "
+                "note": "per-kernel times: ONE extra step right after the timed region runs eagerly with HIP events around every "
+                        "sc_gemm/sc_gemm_splitk launch (the timed steps all replay hipGraphs; `value`/`ms_per_step` do not contain it); `kernel` is the single GEMM kernel with the largest summed time in that step, achieved = its "
                         "2*M*N*K*batch flops / its event time; the split-K entries of by_kernel time two launches (product + "
                         "splitk_reduce_kernel) in one interval and are therefore not eligible as `kernel`; traffic: "
                         "HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_train_step_pmc_traffic.json: "
@@ -514,12 +514,15 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if args.workload == "asr_train_step":
-            wl.step(True, instrument=(i == args.steps // 2))  # one eager, event-instrumented step inside the timed region
-        else:
-            wl.step(True)
+        wl.step(True)  # every timed step is the same replayed step
     fence()
     elapsed = time.perf_counter() - t0
+    if args.workload == "asr_train_step":
+        # one more step, eager, with HIP events around every GEMM launch: the roofline's per-kernel times.  It runs right AFTER the timed
+        # region (it takes about twice a replayed step and, on several ranks, uses the hook-launched all-reduce path), in the same
+        # process, on the same weights and inputs; every rank runs it (its collectives need all of them), rank 0 reports its events.
+        wl.step(False, instrument=True)
+        fence()
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

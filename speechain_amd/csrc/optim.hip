@@ -4,7 +4,7 @@
 // extra passes over the 312 MB of gradients (g*g temporaries for the norm, g *= coef) become two launches and ONE pass:
 //   sc_grad_sumsq  sum of squares of every bucket, two-stage and deterministic, finished in float64; also advances the step counter
 //   sc_adam_step   p, m, v updated in place from g * clip_coef, clip_coef = min(1, max_norm / (||g|| + 1e-6)) formed per thread from
-//                  the scalar (the clipped gradient itself is never written)
+//                  the scalar (the clipped gradient itself is never written); a step whose norm is inf / nan is skipped
 // Parameters, first and second moments live in flat float32 buffers with the layout of the gradient buckets.  HBM-bound:
 // 4 reads + 3 writes of 4 bytes per parameter.
 #include "sc_common.h"
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(Buckets b, double* part
   if (threadIdx.x == 0) partial[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 
-// one workgroup: sums the partials in a fixed order; state[0] = ||g||^2, state[1] = clip coefficient, state[2] = step (advanced here)
+// one workgroup: sums the partials in a fixed order; state[0] = ||g||^2, state[1] = clip coefficient, state[2] = step (advanced here).
+// A norm that is not finite (an overflowed bf16 step) SKIPS the update as the reference does (abs.py:239-247: "the parameters are not
+// updated in this step"): state[1] = -1 tells adam_step_kernel to return, and the step counter stays.
 __global__ __launch_bounds__(256) void grad_sumsq_finish_kernel(const double* partial, int n, float max_norm, float* state) {
   __shared__ double red[256];
   double s = 0.0;
@@ -65,6 +67,10 @@ __global__ __launch_bounds__(256) void grad_sumsq_finish_kernel(const double* pa
   if (threadIdx.x == 0) {
     const double nsq = red[0];
     state[0] = (float)nsq;
+    if (!isfinite(nsq)) {
+      state[1] = -1.f;
+      return;
+    }
     const double coef = max_norm > 0.f ? (double)max_norm / (sqrt(nsq) + 1e-6) : 1.0;
     state[1] = (float)(coef < 1.0 ? coef : 1.0);
     state[2] += 1.f;
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(Buckets b, const float* 
   const long long start = (long long)(blockIdx.x - b.chunk0[k]) * CHUNK;
   const long long end = min(b.n[k], start + CHUNK);
   const float coef = state[1], step = state[2], lr = *lr_cell;
+  if (coef < 0.f) return;  // skipped step (gradient norm not finite): p, m, v untouched
   // torch.optim.Adam: p -= (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
   const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
   const float step_size = lr / bc1, rsq2 = 1.f / sqrtf(bc2);

@@ -65,12 +65,18 @@ class GradBucketReducer:
         self.cuda = self.device.type == "cuda"
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets: List[dict] = []
+        # Slots start on 16-byte boundaries (the sink-writing kernels use 16-byte stores): a parameter whose element count is not a
+        # multiple of 4 -- a scalar such as the positional encoding's alpha, an odd vocabulary -- is followed by zero padding.  The members
+        # of an `adjacent` group stay back to back (one fused kernel writes them as ONE matrix, so only the group's start matters).
+        self._glued = {id(q) for g in group_of.values() for q in g[1:]}
         cur, cur_n = [], 0
         for p in self.params:
             assert p.dtype == torch.float32, "master parameters are float32"
-            if cur and cur_n + p.numel() > cap:
+            if cur and cur_n + p.numel() > cap and id(p) not in self._glued:
                 self._make_bucket(cur)
                 cur, cur_n = [], 0
+            if id(p) not in self._glued:
+                cur_n = (cur_n + 3) // 4 * 4
             cur.append(p)
             cur_n += p.numel()
         if cur:
@@ -82,20 +88,24 @@ class GradBucketReducer:
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
 
     def _make_bucket(self, plist):
-        n = sum(p.numel() for p in plist)
-        flat = torch.zeros(n, dtype=torch.float32, device=self.device)
-        off = 0
-        views = []
+        offsets, off = [], 0
         for p in plist:
-            v = flat[off: off + p.numel()].view_as(p)
+            if id(p) not in self._glued:
+                off = (off + 3) // 4 * 4
+            offsets.append(off)
+            off += p.numel()
+        flat = torch.zeros(off, dtype=torch.float32, device=self.device)  # (padding stays zero: no kernel writes it)
+        views = []
+        for p, o in zip(plist, offsets):
+            v = flat[o: o + p.numel()].view_as(p)
             p.grad = v
             views.append(v)
             if self.use_sinks:
                 from speechain_amd.functional import GradSinks
 
-                GradSinks.register(p, flat, off)
-            off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, ready=0, views=views, index={id(p): i for i, p in enumerate(plist)}))
+                GradSinks.register(p, flat, o)
+        self.buckets.append(dict(params=plist, flat=flat, ready=0, views=views, offsets=offsets,
+                                 index={id(p): i for i, p in enumerate(plist)}))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -151,13 +161,11 @@ class GradBucketReducer:
             self.flat_params = []
             with torch.no_grad():
                 for b in self.buckets:
-                    flat = torch.empty_like(b["flat"])
-                    off = 0
-                    for p in b["params"]:
+                    flat = torch.zeros_like(b["flat"])  # (padding elements: zero parameter, zero gradient, zero moments for ever)
+                    for p, off in zip(b["params"], b["offsets"]):
                         v = flat[off: off + p.numel()].view_as(p)
                         v.copy_(p.data)
                         p.data = v
-                        off += p.numel()
                     self.flat_params.append(flat)
             if self.use_sinks:
                 from speechain_amd.functional import weights

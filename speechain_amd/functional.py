@@ -128,10 +128,36 @@ class _Cast(torch.autograd.Function):
 
 
 class _WeightCache:
-    """(fused) compute-dtype copies of parameters, refreshed when a parameter's version counter moves."""
+    """(fused) compute-dtype copies of parameters, refreshed when a parameter's version counter moves.
+
+    An entry is current while every source parameter still has the (version counter, address) it was made from AND the cache's
+    `epoch` has not moved.  An optimizer that writes parameters with a raw kernel (``speechain_amd.optim.FusedAdam``: torch's
+    version counters do not see it) calls :meth:`mark_stale` after its update; :meth:`refresh` rebuilds EVERY entry -- bf16
+    and float32 matrices, their transposes, and the concatenated bias vectors -- in place (same buffers, so a captured hipGraph
+    that holds their addresses keeps working) in at most two launches and marks them current."""
 
     def __init__(self):
         self.store = {}
+        self.epoch = 0
+        self._desc = {}  # per output dtype: (signature, device descriptor table, records, tiles) of the last refresh
+
+    def _ver(self, params):
+        return (self.epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+
+    def mark_stale(self):
+        """Every cached copy is rebuilt on its next use (or by the next :meth:`refresh`).  Host-side flag only."""
+        self.epoch += 1
+
+    def _lookup(self, key, params):
+        hit = self.store.get(key)
+        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
+            return None  # an id() was recycled by a different (newer) parameter object: the entry is dead
+        return hit
+
+    def _put(self, key, params, buf):
+        if len(self.store) > 4096:  # entries of dead parameters (models created and dropped) are not worth keeping
+            self.store = {k: v for k, v in self.store.items() if all(r() is not None for r in v[2])}
+        self.store[key] = (self._ver(params), buf, tuple(weakref.ref(p) for p in params))
 
     def fused(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
         """Rows of all `params` (each (n_i, K) float32) stacked into one (sum n_i, K) matrix of `dtype`."""
@@ -139,11 +165,8 @@ class _WeightCache:
             return params[0].detach()
         cacheable = all(p.is_leaf for p in params)  # derived tensors (e.g. reshaped conv weights) are cast on the fly
         key = (tuple(id(p) for p in params), dtype)
-        ver = tuple((p._version, p.data_ptr()) for p in params)
-        hit = self.store.get(key) if cacheable else None
-        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
-            hit = None  # an id() was recycled by a different (newer) parameter object: the entry is stale
-        if hit is not None and hit[0] == ver:
+        hit = self._lookup(key, params) if cacheable else None
+        if hit is not None and hit[0] == self._ver(params):
             return hit[1]
         K = params[0].size(1)
         rows = sum(p.size(0) for p in params)
@@ -154,9 +177,7 @@ class _WeightCache:
             lib.call("sc_cast", F32, BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r * K), src.numel(), stream())
             r += p.size(0)
         if cacheable:
-            if len(self.store) > 4096:  # entries of dead parameters (models created and dropped) are not worth keeping
-                self.store = {k: v for k, v in self.store.items() if all(r() is not None for r in v[2])}
-            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+            self._put(key, params, buf)
         return buf
 
     def fused_t(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
@@ -164,11 +185,8 @@ class _WeightCache:
         the fast k-contiguous ("NT") GEMM form instead of reading W with its contraction index strided."""
         cacheable = all(p.is_leaf for p in params)
         key = (tuple(id(p) for p in params), dtype, "T")
-        ver = tuple((p._version, p.data_ptr()) for p in params)
-        hit = self.store.get(key) if cacheable else None
-        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
-            hit = None
-        if hit is not None and hit[0] == ver:
+        hit = self._lookup(key, params) if cacheable else None
+        if hit is not None and hit[0] == self._ver(params):
             return hit[1]
         K = params[0].size(1)
         rows = sum(p.size(0) for p in params)
@@ -179,64 +197,76 @@ class _WeightCache:
             lib.call("sc_cast_transpose", BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r), p.size(0), K, rows, stream())
             r += p.size(0)
         if cacheable:
-            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+            self._put(key, params, buf)
         return buf
 
     def vector(self, params: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
-        """float32 concatenation of bias vectors (None if there is no bias)."""
-        if params[0] is None:
+        """float32 concatenation of bias vectors (None if there is no bias).  The biases of one fused call are all present or all
+        absent (the drop-in modules never mix them; `linear` checks)."""
+        if all(p is None for p in params):
             return None
+        if any(p is None for p in params):
+            raise ValueError("a fused linear call needs a bias on every stacked weight or on none")
         if len(params) == 1:
             return params[0].detach()
+        cacheable = all(p.is_leaf for p in params)
         key = (tuple(id(p) for p in params), "vec")
-        ver = tuple((p._version, p.data_ptr()) for p in params)
-        hit = self.store.get(key)
-        if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
+        hit = self._lookup(key, params) if cacheable else None
+        if hit is not None and hit[0] == self._ver(params):
             return hit[1]
-        buf = torch.cat([p.detach() for p in params])
-        if all(p.is_leaf for p in params):
-            self.store[key] = (ver, buf, tuple(weakref.ref(p) for p in params))
+        if hit is not None:  # rebuilt in place: a captured graph may hold the buffer's address
+            buf = torch.cat([p.detach() for p in params], out=hit[1])
+        else:
+            buf = torch.cat([p.detach() for p in params])
+        if cacheable:
+            self._put(key, params, buf)
         return buf
 
-
     def refresh(self):
-        """Re-casts EVERY cached bf16 copy (plain, fused, transposed) of live parameters in one kernel launch and marks them
-        current.  Call once per training step after the optimizer (or at the top of a captured step): the per-call lookups
-        then all hit, replacing ~250 tiny cast launches by one."""
-        ents = [(k, v) for k, v in self.store.items() if k[1] == torch.bfloat16 and all(r() is not None for r in v[2])]
-        if not ents:
-            return
-        sig = tuple((k, v[1].data_ptr()) for k, v in ents)
-        if getattr(self, "_desc_sig", None) != sig:
-            recs, tile0 = [], 0
-            for k, v in ents:
-                buf, params = v[1], [r() for r in v[2]]
-                transposed = len(k) == 3 and k[2] == "T"
-                r = 0
-                for p in params:
-                    rows, cols = p.shape
-                    tx, ty = (cols + 31) // 32, (rows + 31) // 32
-                    if transposed:
-                        rec = (p.data_ptr(), 0, buf.data_ptr() + 2 * r, rows, cols, 0, buf.size(1), tile0, tx)
-                    else:
-                        rec = (p.data_ptr(), buf.data_ptr() + 2 * r * cols, 0, rows, cols, cols, 0, tile0, tx)
-                    recs.append(struct.pack("<QQQiiqqii", *rec))
-                    tile0 += tx * ty
-                    r += rows
-            dev = ents[0][1][1].device
-            self._desc = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
-            self._desc_n, self._desc_tiles, self._desc_sig = len(recs), tile0, sig
-            self._desc_keys = [k for k, _ in ents]
-        for p in {id(r()): r() for _, v in ents for r in v[2]}.values():
-            assert p.is_contiguous() and p.dtype == torch.float32
-        lib.call("sc_cast_weights", BF16, _p(self._desc), self._desc_n, self._desc_tiles, stream())
-        for k, v in ents:
-            self.store[k] = (tuple((r()._version, r().data_ptr()) for r in v[2]), v[1], v[2])
+        """Rebuilds EVERY cached copy of live parameters in place -- one launch for the bf16 matrices (plain, fused, transposed), one
+        for the float32 ones and the concatenated bias vectors -- and marks them current.  Call once per training step after the
+        optimizer (or at the top of a captured step): the per-call lookups then all hit, replacing ~250 tiny launches."""
+        live = [(k, v) for k, v in self.store.items() if all(r() is not None for r in v[2])]
+        groups = {BF16: [(k, v) for k, v in live if k[1] == torch.bfloat16],
+                  F32: [(k, v) for k, v in live if k[1] != torch.bfloat16]}
+        for code, ents in groups.items():
+            if not ents:
+                continue
+            esz = 2 if code == BF16 else 4
+            sig = tuple((k, v[1].data_ptr()) + tuple(r().data_ptr() for r in v[2]) for k, v in ents)
+            cur = self._desc.get(code)
+            if cur is None or cur[0] != sig:
+                recs, tile0 = [], 0
+                for k, v in ents:
+                    buf, params = v[1], [r() for r in v[2]]
+                    transposed = len(k) == 3 and k[2] == "T"
+                    r = 0
+                    for p in params:
+                        assert p.is_contiguous() and p.dtype == torch.float32
+                        if k[1] == "vec":  # a bias: one row of p.numel() columns at element offset r of the concatenation
+                            rows, cols = 1, p.numel()
+                            rec = (p.data_ptr(), buf.data_ptr() + esz * r, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
+                            r += cols
+                        else:
+                            rows, cols = p.shape
+                            if transposed:
+                                rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, buf.size(1), tile0, (cols + 31) // 32)
+                            else:
+                                rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
+                            r += rows
+                        recs.append(struct.pack("<QQQiiqqii", *rec))
+                        tile0 += ((cols + 31) // 32) * ((rows + 31) // 32)
+                dev = ents[0][1][1].device
+                cur = (sig, torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev), len(recs), tile0)
+                self._desc[code] = cur
+            lib.call("sc_cast_weights", code, _p(cur[1]), cur[2], cur[3], stream())
+        for k, v in live:
+            self.store[k] = (self._ver([r() for r in v[2]]), v[1], v[2])
 
     def invalidate(self):
-        """Drops every cached copy (call after parameters were updated behind torch's version counters, e.g. by a
-        replayed hipGraph)."""
+        """Drops every cached copy (buffers included: not for use between the capture and the replays of a hipGraph)."""
         self.store.clear()
+        self._desc = {}
 
 
 weights = _WeightCache()

@@ -5,7 +5,12 @@ reference's ``OptimScheduler.step`` (speechain/optim_sche/abs.py:232-253) -- wit
 over the gradients per step.  Same arithmetic: the norm over ALL gradients (finished in float64), ``coef = min(1, max_norm / (norm +
 1e-6))``, Adam without weight decay / amsgrad, bias corrections from a step counter that lives on the device (so a captured hipGraph
 advances it on every replay), learning rate read from a device cell the scheduler fills.  The clipped gradient is not written back:
-``clip_coef`` holds the factor the update used.
+``clip_coef`` holds the factor the update used.  As in the reference (abs.py:239-247) a step whose gradient norm is not finite is
+SKIPPED: parameters, both moments and the step counter stay as they were, and ``skipped`` reads 1.
+
+The update is a raw kernel, so torch's version counters do not move: ``step()`` therefore marks the cached compute-dtype weight
+copies (``functional.weights``) stale, and the next forward pass rebuilds them -- all of them in two launches if the training loop
+calls ``functional.weights.refresh()`` once per step (a captured step must: its replays never run ``step()`` on the host).
 """
 import ctypes
 from typing import Optional, Tuple
@@ -41,18 +46,26 @@ class FusedAdam:
 
     @property
     def clip_coef(self) -> torch.Tensor:
-        return self.state[1]
+        """The factor the last update multiplied the gradients by (0 for a skipped step)."""
+        return self.state[1].clamp(min=0.0)
+
+    @property
+    def skipped(self) -> torch.Tensor:
+        """1.0 if the last step was skipped because its gradient norm was not finite (device scalar; reading it synchronises)."""
+        return (self.state[1] < 0).float()
 
     def step(self):
         n = len(self.grads)
         lib.call("sc_grad_sumsq", n, self._g, self._n, self.max_grad_norm, self.state.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream())
         lib.call("sc_adam_step", n, self._p, self._g, self._m, self._v, self._n, self.lr.data_ptr(), float(self.betas[0]), float(self.betas[1]),
                  float(self.eps), self.state.data_ptr(), stream())
+        from speechain_amd.functional import weights
+        weights.mark_stale()  # the kernel wrote the parameters behind torch's version counters
 
     def state_of(self, param: torch.Tensor):
         """(exp_avg, exp_avg_sq) views of one parameter, shaped like it (for checkpoints in torch.optim.Adam's layout)."""
         for b, m, v in zip(self.reducer.buckets, self.exp_avg, self.exp_avg_sq):
             if id(param) in b["index"]:
-                off = sum(q.numel() for q in b["params"][: b["index"][id(param)]])
+                off = b["offsets"][b["index"][id(param)]]
                 return m[off: off + param.numel()].view_as(param), v[off: off + param.numel()].view_as(param)
         raise KeyError("parameter is not managed by this optimizer")
