@@ -184,6 +184,24 @@ int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M
                    float alpha, int splitk, int accumulate, float* colsum, void* workspace, long long ws_bytes,
                    hipStream_t stream);
 
+/* Grouped weight gradients: for g < n, dW[g] (n_out[g] x n_in[g], f32, dense) = dz[g]^T x[g] and -- where db[g] is not null --
+ * db[g] (n_out[g], f32) = column sums of dz[g]: the grad_weight / grad_bias halves of the nn.Linear backward of every layer of the
+ * transformer path (attention.py:53-59, feed_forward.py:62-84, postnet/token.py:35-37, model/ar_asr.py:224-228, prenet/conv2d.py:171-203),
+ * which the reference's autograd runs one layer at a time, computed together: every workgroup owns one output tile of one layer and runs
+ * the whole contraction over the tokens (no split-K, no partial sums, deterministic).  dz[g] is (tokens[g], n_out[g]) bf16 with row stride
+ * ldz[g], x[g] is (tokens[g], n_in[g]) bf16 with row stride ldx[g].  The nine arrays are HOST arrays of n entries (device pointers and
+ * sizes); every problem must satisfy sc_wgrad_grouped_supported (n_out, n_in, ldz, ldx multiples of 8, tokens a multiple of 32,
+ * 16-byte aligned pointers).  tile: 0 = choose, 128 / 256 = force the output tile edge.  `workspace` (device memory,
+ * sc_wgrad_grouped_workspace(n, n_out, n_in) bytes, 16-byte aligned) receives the schedule: the problems cut into units of at most 16
+ * tiles, dealt to the 8 XCDs by work; it is filled by small launches that carry the entries as kernel arguments, so the call makes
+ * no host-to-device copy and can be captured into a hipGraph. */
+int sc_wgrad_grouped_supported(int n_out, int n_in, int tokens, long long ldz, long long ldx);
+int sc_wgrad_grouped_last_tile(void); /* measurement aid: tile edge the calling thread's last sc_wgrad_grouped call used */
+long long sc_wgrad_grouped_workspace(int n, const int* n_out, const int* n_in);
+int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, float* const* dW, float* const* db, const int* n_out,
+                     const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, int tile, void* workspace,
+                     long long ws_bytes, hipStream_t stream);
+
 /* nn.LayerNorm over the last dim D of an (R, D) matrix (encoder.py:97-98,291-292; decoder.py:90-92; pos_enc.py:94-95);
  * mean/rstd (R,) are saved for the backward pass (may be null).  Backward returns dx and the parameter gradients;
  * `workspace` needs sc_layernorm_bwd_workspace(R, D) bytes.  dres (nullable, (R, D) in `dtype`) is added to dx before the store: in a

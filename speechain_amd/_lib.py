@@ -86,6 +86,10 @@ class _Lib:
             rc = getattr(dll, name)(*args)
             e1.record()
             rec.append((e0, e1))
+            if self.kernel_log is not None and name == "sc_wgrad_grouped":
+                self.kernel_log.append(13 if dll.sc_wgrad_grouped_last_tile() == 256 else 14)
+                if self.shape_log is not None:
+                    self.shape_log.append((int(sum(args[5])), int(max(args[6])), int(max(args[7])), args[0]))
             if self.kernel_log is not None and name in ("sc_gemm", "sc_gemm_splitk"):
                 self.kernel_log.append(dll.sc_gemm_last_kernel())
                 if self.shape_log is not None:

@@ -20,6 +20,7 @@
 // are bank-conflict free; row-contiguous operands are transposed on their way into LDS.
 #include "sc_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -748,7 +749,16 @@ typedef __attribute__((address_space(3))) void* sc_lptr_t;
 //   <2,2,2> 128 x 128, 4 waves, 4 stages (64 KB, 2 workgroups / CU)   -- many small tiles for narrow outputs
 //   <2,4,4> 256 x 256, 8 waves, 4 stages (128 KB, 1 workgroup / CU)   -- half the L2->LDS traffic per flop; the mid-size
 //           GEMMs of this model (M ~ 8000, K = 512) are bound by exactly that traffic, not by the matrix cores
-template <int WM, int WN, int MI>
+// PF: how the MFMA fragments are fetched from LDS.
+//   0  per K tile: wait + barrier, then read fragments, then multiply (the reads' latency is exposed twice per tile; with one
+//      wave per SIMD -- every launch of at most 256 workgroups of 4 waves -- nothing else fills it: ~1000 cycles per tile for
+//      256 cycles of MFMA work)
+//   1  software-pipelined by half tiles: the fragments of (tile, ks+1) are read while (tile, ks) is multiplied; the barrier
+//      that publishes tile t+1 sits between the two halves of tile t                       (2 x (MI + 2) fragments live)
+//   2  software-pipelined by whole tiles: tile t+1's fragments are read while tile t is multiplied (4 x (MI + 2) fragments)
+// In 1 and 2 the barrier of iteration t publishes tile t+1 (not t), all waves have tile t in registers by then, so the stage of
+// tile t is free and receives tile t + STAGES: STAGES - 1 tiles in flight behind the one being read.
+template <int WM, int WN, int MI, int PF>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf16_nt_dma_kernel(GemmArgs p) {
   constexpr int NW = WM * WN, TM = WM * MI * 32, TN = WN * 64;
   constexpr int STAGES = 4, STAGE_ELEMS = (TM + TN) * BK16;
@@ -813,6 +823,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   if (nk > 0) SC_DMA_ISSUE(0);
   if (nk > 1) SC_DMA_ISSUE(1);
   if (nk > 2) SC_DMA_ISSUE(2);
+  if (PF != 0 && nk > 3) SC_DMA_ISSUE(3);
 
   // fragment read offsets (elements) inside an operand tile: row = base + li, 16-byte chunk (2*ks + h) swizzled
   int aoff[MI][2], boff[2][2];
@@ -831,6 +842,43 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   }
 
   constexpr int LPT = ACH + BCH;  // DMA instructions per wave per tile
+#define SC_WAIT_TILES(AHEAD)                                                                  \
+  do {                                                                                        \
+    const int ah_ = (AHEAD);                                                                  \
+    if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");              \
+    else if (ah_ == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");         \
+    else if (ah_ == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+  } while (0)
+#define SC_FRAGS(T, KS, FA, FB)                                                               \
+  do {                                                                                        \
+    const unsigned short* as_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                         \
+    const unsigned short* bs_ = as_ + TM * BK16;                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) FA[i_] = *(const bf16x8_t*)(as_ + aoff[i_][KS]); \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) FB[j_] = *(const bf16x8_t*)(bs_ + boff[j_][KS]);  \
+  } while (0)
+#define SC_MMA(FA, FB)                                                                        \
+  do {                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                         \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                        \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i_], FB[j_], acc[i_][j_], 0, 0, 0); \
+  } while (0)
+// tile T+1 has landed for this wave; after the barrier it is visible to all, and every wave holds tile T in registers
+#define SC_PUBLISH_NEXT(T)                                                                    \
+  do {                                                                                        \
+    SC_WAIT_TILES(min(STAGES - 2, nk - 2 - (T)));                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    if ((T) + STAGES < nk) SC_DMA_ISSUE((T) + STAGES);                                        \
+  } while (0)
+#define SC_PUBLISH_STEADY(T)                                                                  \
+  do {                                                                                        \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    SC_DMA_ISSUE((T) + STAGES);                                                               \
+  } while (0)
+  if constexpr (PF == 0) {
   for (int t = 0; t < nk; ++t) {
     // tile t must have landed: every wave waits for its own DMA (counted: later tiles stay in flight), then the barrier
     // makes all waves' pieces visible and proves everyone is done reading the stage that tile t+3 overwrites.
@@ -855,6 +903,73 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
+  } else if constexpr (PF == 1) {
+    bf16x8_t fa0[MI], fb0[2], fa1[MI], fb1[2];
+    SC_WAIT_TILES(min(STAGES - 1, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    SC_FRAGS(0, 0, fa0, fb0);
+    int t = 0;
+    // steady state, branch-free (a conditional around the reads makes the compiler wait lgkmcnt(0) at the merge point, which
+    // serialises reads and MFMAs again): tile t + STAGES exists, so every wait is the full-depth one
+    for (; t + STAGES < nk; ++t) {
+      SC_FRAGS(t, 1, fa1, fb1);
+      SC_MMA(fa0, fb0);
+      SC_PUBLISH_STEADY(t);
+      SC_FRAGS(t + 1, 0, fa0, fb0);
+      SC_MMA(fa1, fb1);
+    }
+    for (; t < nk; ++t) {
+      SC_FRAGS(t, 1, fa1, fb1);
+      SC_MMA(fa0, fb0);
+      if (t + 1 < nk) {
+        SC_PUBLISH_NEXT(t);
+        SC_FRAGS(t + 1, 0, fa0, fb0);
+      }
+      SC_MMA(fa1, fb1);
+    }
+  } else {
+    bf16x8_t fa00[MI], fb00[2], fa01[MI], fb01[2], fa10[MI], fb10[2], fa11[MI], fb11[2];
+    SC_WAIT_TILES(min(STAGES - 1, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    SC_FRAGS(0, 0, fa00, fb00);
+    SC_FRAGS(0, 1, fa01, fb01);
+    int t = 0;
+    for (; t + STAGES + 1 < nk; t += 2) {  // steady state, branch-free: tiles t + STAGES and t + 1 + STAGES exist
+      SC_PUBLISH_STEADY(t);
+      SC_FRAGS(t + 1, 0, fa10, fb10);
+      SC_FRAGS(t + 1, 1, fa11, fb11);
+      SC_MMA(fa00, fb00);
+      SC_MMA(fa01, fb01);
+      SC_PUBLISH_STEADY(t + 1);
+      SC_FRAGS(t + 2, 0, fa00, fb00);
+      SC_FRAGS(t + 2, 1, fa01, fb01);
+      SC_MMA(fa10, fb10);
+      SC_MMA(fa11, fb11);
+    }
+    for (; t < nk; t += 2) {
+      if (t + 1 < nk) {
+        SC_PUBLISH_NEXT(t);
+        SC_FRAGS(t + 1, 0, fa10, fb10);
+        SC_FRAGS(t + 1, 1, fa11, fb11);
+      }
+      SC_MMA(fa00, fb00);
+      SC_MMA(fa01, fb01);
+      if (t + 1 < nk) {
+        if (t + 2 < nk) {
+          SC_PUBLISH_NEXT(t + 1);
+          SC_FRAGS(t + 2, 0, fa00, fb00);
+          SC_FRAGS(t + 2, 1, fa01, fb01);
+        }
+        SC_MMA(fa10, fb10);
+        SC_MMA(fa11, fb11);
+      }
+    }
+  }
+#undef SC_PUBLISH_STEADY
+#undef SC_WAIT_TILES
+#undef SC_FRAGS
+#undef SC_MMA
+#undef SC_PUBLISH_NEXT
 #undef SC_DMA_ISSUE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become epilogue staging
@@ -953,6 +1068,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
   if (nk > 0) SC_TN_ISSUE(0);
   if (nk > 1) SC_TN_ISSUE(1);
   if (nk > 2) SC_TN_ISSUE(2);
+  if (nk > 3) SC_TN_ISSUE(3);
 
   // bias gradient: column sums of A over the contraction, taken from the landed A tiles by the workgroups of the first
   // N tile.  Thread t reads column chunk t & 15 of k-rows (t >> 4) and (t >> 4) + 16 -- the same ownership as in the
@@ -968,42 +1084,108 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
     csoff[i] = (kr >> 2) * 512 + (kr & 3) * 128 + (((tid & 15) ^ ((kr & 3) << 2)) << 3);
   }
 
+  // Software-pipelined as the NT kernel (PF = 2): the barrier of iteration t publishes tile t+1, whose fragments are read
+  // while tile t is multiplied; the stage of tile t then receives tile t + STAGES.
   constexpr int LPT = 4;  // DMA instructions per wave per tile
-  for (int t = 0; t < nk; ++t) {
-    const int ahead = min(2, nk - 1 - t);
-    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 3 < nk) SC_TN_ISSUE(t + 3);
-    const unsigned short* as = dsmem + (t % STAGES) * STAGE_ELEMS;
-    const unsigned short* bs = as + OPER_ELEMS;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = read_frag16_tr_swz(as, wr * 64 + i * 32, ks, lane);
-        b[i] = read_frag16_tr_swz(bs, wc * 64 + i * 32, ks, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#define SC_WAIT_TILES(AHEAD)                                                                  \
+  do {                                                                                        \
+    const int ah_ = (AHEAD);                                                                  \
+    if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");              \
+    else if (ah_ == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");         \
+    else if (ah_ == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+  } while (0)
+#define SC_FRAGS(T, FA, FB)                                                                   \
+  do {                                                                                        \
+    const unsigned short* as_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                         \
+    const unsigned short* bs_ = as_ + OPER_ELEMS;                                             \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                      \
+        FA[ks_][i_] = read_frag16_tr_swz(as_, wr * 64 + i_ * 32, ks_, lane);                  \
+        FB[ks_][i_] = read_frag16_tr_swz(bs_, wc * 64 + i_ * 32, ks_, lane);                  \
+      }                                                                                       \
+  } while (0)
+#define SC_CSUM(T)                                                                            \
+  do {                                                                                        \
+    if constexpr (decltype(with_csum)::value) {                                               \
+      const unsigned short* as_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                      \
+        const uint4 u_ = *(const uint4*)(as_ + csoff[i_]);                                    \
+        const unsigned w_[4] = {u_.x, u_.y, u_.z, u_.w};                                      \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                    \
+          cs[2 * e_] += __uint_as_float(w_[e_] << 16);                                        \
+          cs[2 * e_ + 1] += __uint_as_float(w_[e_] & 0xffff0000u);                            \
+        }                                                                                     \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+#define SC_MMA(FA, FB)                                                                        \
+  do {                                                                                        \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                      \
+          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[ks_][i_], FB[ks_][j_], acc[i_][j_], 0, 0, 0); \
+  } while (0)
+#define SC_PUBLISH_NEXT(T)                                                                    \
+  do {                                                                                        \
+    SC_WAIT_TILES(min(STAGES - 2, nk - 2 - (T)));                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    if ((T) + STAGES < nk) SC_TN_ISSUE((T) + STAGES);                                         \
+  } while (0)
+#define SC_PUBLISH_STEADY(T)                                                                  \
+  do {                                                                                        \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    SC_TN_ISSUE((T) + STAGES);                                                                \
+  } while (0)
+  // (two instances of the loop, with and without the column sums: a run-time branch around LDS reads inside the steady state makes
+  // the compiler wait for ALL outstanding reads where the paths merge, which serialises fragment reads and MFMAs again)
+  auto main_loop = [&](auto with_csum) {
+    bf16x8_t fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+    if (nk > 0) {
+      SC_WAIT_TILES(min(STAGES - 1, nk - 1));
+      __builtin_amdgcn_s_barrier();
+      SC_FRAGS(0, fa0, fb0);
+      SC_CSUM(0);
     }
-    if (csum) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint4 u = *(const uint4*)(as + csoff[i]);
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cs[2 * e] += __uint_as_float(w[e] << 16);
-          cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+    int t = 0;
+    for (; t + STAGES + 1 < nk; t += 2) {  // steady state, branch-free
+      SC_PUBLISH_STEADY(t);
+      SC_FRAGS(t + 1, fa1, fb1);
+      SC_CSUM(t + 1);
+      SC_MMA(fa0, fb0);
+      SC_PUBLISH_STEADY(t + 1);
+      SC_FRAGS(t + 2, fa0, fb0);
+      SC_CSUM(t + 2);
+      SC_MMA(fa1, fb1);
+    }
+    for (; t < nk; t += 2) {
+      if (t + 1 < nk) {
+        SC_PUBLISH_NEXT(t);
+        SC_FRAGS(t + 1, fa1, fb1);
+        SC_CSUM(t + 1);
+      }
+      SC_MMA(fa0, fb0);
+      if (t + 1 < nk) {
+        if (t + 2 < nk) {
+          SC_PUBLISH_NEXT(t + 1);
+          SC_FRAGS(t + 2, fa0, fb0);
+          SC_CSUM(t + 2);
         }
+        SC_MMA(fa1, fb1);
       }
     }
-  }
+  };
+  if (csum) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
+#undef SC_WAIT_TILES
+#undef SC_FRAGS
+#undef SC_CSUM
+#undef SC_MMA
+#undef SC_PUBLISH_NEXT
+#undef SC_PUBLISH_STEADY
 #undef SC_TN_ISSUE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become staging
@@ -1049,12 +1231,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
   }
 }
 
-template <int WM, int WN, int MI>
-int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
+template <int WM, int WN, int MI, int PF>
+int launch_dma_pf(const GemmArgs& a, int nbatch, hipStream_t stream) {
   constexpr int TM = WM * MI * 32, TN = WN * 64;
   constexpr size_t smem = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short);
   static_assert(smem >= (size_t)WM * WN * 32 * STG_LD * sizeof(float), "operand stages must cover the epilogue staging");
-  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI>;
+  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return sc_set_error(SC_ERR_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1063,6 +1245,17 @@ int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
   hipLaunchKernelGGL(kernel, grid, dim3(64 * WM * WN), smem, stream, a);
   SC_LAUNCH_CHECK("gemm_bf16_nt_dma_kernel");
   return SC_OK;
+}
+
+// Fragment pipelining per tile configuration, from scripts/ab_gemm_pf.sh on the step's shapes (two alternating rounds, one box):
+//   <2,2,2> 128 x 128, one wave per SIMD when the launch has <= 256 workgroups: PF 2   (M = 7968: N = K = 512 11.4 -> 10.4 us,
+//           N = 512, K = 2048 26.9 -> 24.8 us; PF 1 in between)
+//   <2,2,1> 64 x 128: PF 2 (M = 2016, N = 2048, K = 512: 10.8 -> 9.8 us);  <2,1,1> 64 x 64: PF 1 (M = 2016, N = K = 512: 6.8 -> 5.9 us)
+//   <2,4,4> 256 x 256, two waves per SIMD (the partner wave already fills the read latency): PF 0 (7968 x 2048 x 512: 26.5 / 26.2 /
+//           26.4 us for PF 0 / 1 / 2; 8192^3: 1182 / 1353 / 1265 us)
+template <int WM, int WN, int MI, int PF>
+int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
+  return launch_dma_pf<WM, WN, MI, PF>(a, nbatch, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1234,8 +1427,8 @@ int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const ch
 static thread_local int g_last_gemm_kernel = 0;
 static const char* const kGemmKernelNames[] = {
     "none",
-    "gemm_bf16_nt_dma_kernel<2, 2, 2>",
-    "gemm_bf16_nt_dma_kernel<2, 4, 4>",
+    "gemm_bf16_nt_dma_kernel<2, 2, 2, 2>",
+    "gemm_bf16_nt_dma_kernel<2, 4, 4, 0>",
     "gemm_bf16_kernel<false, false>",
     "gemm_bf16_kernel<false, true>",
     "gemm_bf16_kernel<true, false>",
@@ -1244,8 +1437,10 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_kernel<true, true> (split-K) + splitk_reduce_kernel",
     "gemm_bf16_tn_dma_splitk_kernel + splitk_reduce_kernel",
     "gemm_bf16_kernel (split-K, other layout) + splitk_reduce_kernel",
-    "gemm_bf16_nt_dma_kernel<2, 2, 1>",
-    "gemm_bf16_nt_dma_kernel<2, 1, 1>",
+    "gemm_bf16_nt_dma_kernel<2, 2, 1, 2>",
+    "gemm_bf16_nt_dma_kernel<2, 1, 1, 1>",
+    "wgrad_grouped_kernel<2, 4, 4>",
+    "wgrad_grouped_kernel<2, 2, 2>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 SC_API const char* sc_gemm_kernel_name(int id) {
@@ -1300,16 +1495,16 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
-      if (big >= 160 && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4>(a, nb, stream); }
+      if (big >= 160 && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4, 0>(a, nb, stream); }
       // Very few tiles (the decoder's M = 2016, N = 512 products: 64 tiles of 128 x 128, 128 of 64 x 128): 64 x 64 tiles, two waves each,
       // put a workgroup on every CU.  Step-level A/B (40 steps, alternating): 12.35 / 12.36 / 12.55 ms with them vs 12.60 / 12.61 / 12.69
       // without; thresholds of 80, 128 and 192 tiles measure the same (12.53 .. 12.64 on another box), 256 hurts (12.99).
       // SC_GEMM_T64=<max tiles> overrides (0 switches the variant off).
       static const long long t64max = [] { const char* e = getenv("SC_GEMM_T64"); return e ? atoll(e) : 80LL; }();
-      if (t128 <= t64max) { g_last_gemm_kernel = 12; return launch_dma<2, 1, 1>(a, nb, stream); }
-      if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1>(a, nb, stream); }
+      if (t128 <= t64max) { g_last_gemm_kernel = 12; return launch_dma<2, 1, 1, 1>(a, nb, stream); }
+      if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1, 2>(a, nb, stream); }
       g_last_gemm_kernel = 1;
-      return launch_dma<2, 2, 2>(a, nb, stream);
+      return launch_dma<2, 2, 2, 2>(a, nb, stream);
     }
     g_last_gemm_kernel = 3 + (ta ? 2 : 0) + (tb ? 1 : 0);
     if (!ta && !tb) return launch(gemm_bf16_kernel<false, false>, a, nb, stream, "gemm_bf16<NT>");

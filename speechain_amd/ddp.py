@@ -130,9 +130,10 @@ class GradBucketReducer:
             return
         if self.cuda:
             if self.use_sinks:  # LayerNorm parameter gradients queued for the end of backward belong to the slots too
-                from speechain_amd.functional import _LnFinish
+                from speechain_amd.functional import _LnFinish, _WgradQueue
 
                 _LnFinish.flush()
+                _WgradQueue.flush()  # (weight gradients deferred to one grouped launch: they must be in the slots now)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):

@@ -308,6 +308,7 @@ class GradSinks:
     def begin_step(cls):
         cls.step += 1
         _LnFinish.reset()  # (entries of a backward call that raised must not survive into the next step)
+        _WgradQueue.reset()
 
     @classmethod
     def take(cls, params: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -338,8 +339,12 @@ class _Side:
     streams = {}
     enabled = True
 
-    def __init__(self, ref: torch.Tensor):
+    def __init__(self, ref: torch.Tensor, wgrad_only: bool = False):
+        """`wgrad_only`: the side work consists of weight-gradient products only -- no fork when those are deferred to the grouped
+        launch anyway (gradient sinks registered, bf16)."""
         self.on = _Side.enabled and ref.is_cuda
+        if wgrad_only and _WgradQueue.enabled and GradSinks.table and ref.dtype == torch.bfloat16:
+            self.on = False
         if self.on:
             key = ref.device.index
             if key not in _Side.streams:
@@ -371,6 +376,56 @@ import os as _os
 _WGRAD_WG_TARGET = int(_os.environ.get("SC_WGRAD_WG_TARGET", "256"))
 
 
+class _WgradQueue:
+    """Weight-gradient products whose outputs are gradient-bucket slots, deferred and computed TOGETHER by one grouped launch
+    (``sc_wgrad_grouped``, csrc/wgrad_grouped.hip) when the running backward call finishes (autograd engine callback) or when the
+    reducer is about to ship a bucket.  One layer's dW = dz^T x is a small output over a long contraction -- 4 to 64 tiles for 256
+    CUs, which is why it used to be cut along the contraction (partial slabs + a second launch, 94 times per step); all layers of a
+    backward pass together are ~1000 tiles of 256 x 256, each a full contraction.  Nothing reads a bucket slot before the step's
+    backward has ended, so the result is the same.  Entries hold raw addresses of the outputs (a lingering reference to the slot
+    views would make autograd's accumulation clone them before they are written) and keep the operands alive."""
+
+    pending = []   # (dz address, x address, dW address, db address or 0, n_out, n_in, tokens, ldz, ldx)
+    keep = []      # operand tensors
+    armed = False
+    enabled = _os.environ.get("SC_WGRAD_GROUPED", "1") == "1"  # (A/B knob)
+
+    @classmethod
+    def add(cls, dz: torch.Tensor, x2: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor]):
+        cls.pending.append((dz.data_ptr(), x2.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, dz.size(1), x2.size(1),
+                            dz.size(0), dz.stride(0), x2.stride(0)))
+        cls.keep.append((dz, x2))
+        if not cls.armed:
+            cls.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+
+    @classmethod
+    def reset(cls):
+        cls.pending.clear()
+        cls.keep.clear()
+        cls.armed = False
+
+    @classmethod
+    def flush(cls):
+        """Launches the pending products on the current stream."""
+        cls.armed = False
+        if not cls.pending:
+            return
+        import ctypes
+
+        n = len(cls.pending)
+        col = lambda i, ct: (ct * n)(*[e[i] for e in cls.pending])
+        if lib.timing is not None and "sc_wgrad_grouped" in lib.timing and lib.flop_log is not None:
+            lib.flop_log.append(sum(2.0 * e[4] * e[5] * e[6] for e in cls.pending))
+        n_out, n_in = col(4, ctypes.c_int), col(5, ctypes.c_int)
+        ws = torch.empty(lib.value("sc_wgrad_grouped_workspace", n, n_out, n_in), dtype=torch.uint8, device=cls.keep[0][0].device)
+        lib.call("sc_wgrad_grouped", n, col(0, ctypes.c_void_p), col(1, ctypes.c_void_p), col(2, ctypes.c_void_p), col(3, ctypes.c_void_p),
+                 n_out, n_in, col(6, ctypes.c_int), col(7, ctypes.c_longlong), col(8, ctypes.c_longlong), 0, ws.data_ptr(), ws.numel(),
+                 stream())
+        cls.pending.clear()
+        cls.keep.clear()
+
+
 def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.Tensor] = (), bias: bool = False,
           bias_params: Sequence[torch.Tensor] = ()):
     """dW (N, K) float32 = dz^T x for dz (M, N), x (M, K), written into the registered gradient slots of `params` when they
@@ -380,6 +435,18 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
     M, N = dz.shape
     K = x2.size(1)
     sink = GradSinks.take(params) if params else None
+    if (code == BF16 and sink is not None and _WgradQueue.enabled and dz.stride(1) == 1 and x2.stride(1) == 1
+            and lib.value("sc_wgrad_grouped_supported", N, K, M, dz.stride(0), x2.stride(0))
+            and dz.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and sink.data_ptr() % 16 == 0):
+        bsink = GradSinks.take(bias_params) if (bias and bias_params) else None
+        if not bias or bsink is not None:
+            # both outputs are bucket slots: the product joins the grouped launch at the end of this backward call
+            dW = sink.view(N, K)
+            _WgradQueue.add(dz, x2, dW, bsink)
+            return (dW, bsink) if bias else dW
+        dW = sink.view(N, K)  # (a bias outside the buckets: its column sums are taken now)
+        _WgradQueue.add(dz, x2, dW, None)
+        return dW, _colsum(dz, ())
     dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     # (at most 16 slices for the transformer's products, M ~ 8000; up to 64 for the prenet's conv weight gradient, whose contraction
@@ -476,7 +543,7 @@ class _Linear(torch.autograd.Function):
         dres = dy if has_res else None
         dz = _dropout_apply(dy2, drop_p, seed, off)
         W = weights.fused(ws, x2.dtype)
-        side = _Side(x2)
+        side = _Side(x2, wgrad_only=True)
         with side:  # parameter gradients next to the data gradient
             # dW = dz^T x, and db = column sums of dz out of the same launch
             dW, db = wgrad(code, dz, x2, ws, bias=True, bias_params=ctx.bias_params if all(has_b) else ()) if any(has_b) \
@@ -595,7 +662,7 @@ class _FFN(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dz = _dropout_apply(dy2, p_res, s2, o2)
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
-        side = _Side(x2)
+        side = _Side(x2, wgrad_only=True)
         with side:
             dW2, db2 = wgrad(code, dz, h, [w2], bias=True, bias_params=ctx.bias_params[1]) if has_b2 \
                 else (wgrad(code, dz, h, [w2]), None)

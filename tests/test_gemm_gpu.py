@@ -43,7 +43,7 @@ def test_few_tile_products_on_64x64_tiles(M, N, K, res):
     C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
     Fn.gemm(Fn.BF16, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, bias=bias, aux=Fn._p(R) if res else None, ldaux=N, aux_mode=1 if res else 0)
     from speechain_amd._lib import lib
-    assert lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode() == "gemm_bf16_nt_dma_kernel<2, 1, 1>"
+    assert lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode() == "gemm_bf16_nt_dma_kernel<2, 1, 1, 1>"
     ref = A.double() @ B.double().t() + bias.double() + (R.double() if res else 0)
     assert torch.allclose(C.double(), ref, **_tol(torch.bfloat16, K)), float((C.double() - ref).abs().max())
 
@@ -217,3 +217,62 @@ def test_pre_gradient_output_and_multiply_mode(dtype, act, p):
     Fn.gemm(Fn.dcode(A2), Fn._p(A2), Fn._p(B2), Fn._p(C), M, N, K, K, K, N, aux=Fn._p(g), ldaux=N, aux_mode=3)
     ref = (A2.double() @ B2.double().t()) * g.double()
     assert torch.allclose(C.double(), ref, **_tol(dtype, K)), float((C.double() - ref).abs().max())
+
+
+def _grouped(problems, tile):
+    """problems: list of (dz, x, want_db).  Returns [(dW, db or None)] computed by ONE sc_wgrad_grouped call."""
+    import ctypes
+
+    from speechain_amd._lib import lib, stream
+
+    n = len(problems)
+    outs = []
+    for dz, x, want_db in problems:
+        dW = torch.full((dz.size(1), x.size(1)), float("nan"), device="cuda")
+        db = torch.full((dz.size(1),), float("nan"), device="cuda") if want_db else None
+        outs.append((dW, db))
+    arr = lambda ct, vals: (ct * n)(*vals)
+    n_out, n_in = arr(ctypes.c_int, [p[0].size(1) for p in problems]), arr(ctypes.c_int, [p[1].size(1) for p in problems])
+    ws = torch.empty(lib.value("sc_wgrad_grouped_workspace", n, n_out, n_in), dtype=torch.uint8, device="cuda")
+    lib.call("sc_wgrad_grouped", n, arr(ctypes.c_void_p, [p[0].data_ptr() for p in problems]),
+             arr(ctypes.c_void_p, [p[1].data_ptr() for p in problems]), arr(ctypes.c_void_p, [o[0].data_ptr() for o in outs]),
+             arr(ctypes.c_void_p, [o[1].data_ptr() if o[1] is not None else 0 for o in outs]),
+             n_out, n_in, arr(ctypes.c_int, [p[0].size(0) for p in problems]), arr(ctypes.c_longlong, [p[0].stride(0) for p in problems]),
+             arr(ctypes.c_longlong, [p[1].stride(0) for p in problems]), tile, ws.data_ptr(), ws.numel(), stream())
+    return outs
+
+
+@pytest.mark.parametrize("tile", [128, 256, 0])
+def test_grouped_weight_gradients(tile):
+    """sc_wgrad_grouped: a mixed list of layers in one call -- ragged output sizes (tiles hanging over both edges), different token
+    counts (1 .. 40 K tiles: prologue-only, tail-only and steady-state loops), strided operands (q|k|v side by side), with and
+    without the bias gradient -- against float64 dz^T x and column sums.  bf16 products accumulate in f32 in token order."""
+    shapes = [(512, 512, 32 * 31), (1536, 512, 992), (40, 72, 32), (5000 // 8 * 8, 512, 64), (264, 136, 96), (2048, 512, 1280),
+              (128, 128, 128), (8, 8, 160), (520, 2048, 320)]
+    problems = []
+    for i, (n_out, n_in, tok) in enumerate(shapes):
+        wide = _mk((tok, n_out + 24), torch.bfloat16, 100 + i)
+        dz = wide[:, 16:16 + n_out] if i % 3 == 1 else _mk((tok, n_out), torch.bfloat16, 100 + i)  # some with a row stride > n_out
+        x = _mk((tok, n_in), torch.bfloat16, 200 + i)
+        problems.append((dz, x, i % 2 == 0))
+    # more units than one table-writer launch carries (56)
+    for i in range(38):
+        problems.append((_mk((64, 24), torch.bfloat16, 300 + i), _mk((64, 16), torch.bfloat16, 400 + i), i % 4 == 0))
+    outs = _grouped(problems, tile)
+    for (dz, x, want_db), (dW, db) in zip(problems, outs):
+        ref = dz.double().t() @ x.double()
+        tok = dz.size(0)
+        assert torch.allclose(dW.double(), ref, atol=2e-3 * math.sqrt(tok), rtol=1e-3), (dz.shape, x.shape, float((dW.double() - ref).abs().max()))
+        if want_db:
+            assert torch.allclose(db.double(), dz.double().sum(0), atol=1e-3 * math.sqrt(tok), rtol=1e-4), (dz.shape, float((db.double() - dz.double().sum(0)).abs().max()))
+
+
+def test_grouped_weight_gradients_refuse_unsupported_shapes():
+    from speechain_amd._lib import lib
+
+    assert lib.value("sc_wgrad_grouped_supported", 512, 512, 7968, 512, 512) == 1
+    assert lib.value("sc_wgrad_grouped_supported", 512, 512, 100, 512, 512) == 0   # tokens not a multiple of 32
+    assert lib.value("sc_wgrad_grouped_supported", 31, 512, 64, 31, 512) == 0      # odd feature count
+    assert lib.value("sc_wgrad_grouped_supported", 512, 512, 64, 500, 512) == 0    # row stride below the width
+    with pytest.raises(RuntimeError, match="not supported"):
+        _grouped([(_mk((100, 64), torch.bfloat16, 1), _mk((100, 64), torch.bfloat16, 2), False)], 0)
