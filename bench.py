@@ -177,6 +177,52 @@ class ASRTrainStepWorkload:
         # more than one rank: backward is captured in pieces and each piece's finished buckets are all-reduced under the next one
         self.segmented = self.reducer.multi and os.environ.get("BENCH_NO_SEGMENTS", "0") != "1"
         self.g_pieces, self.piece_buckets = [], []
+        # The head of a step (frontend -> normalisation -> SpecAugment; eager, its index draws read lengths on the host) depends on the
+        # data only, so the head of batch i+1 runs on a second stream while the replayed graphs of batch i occupy the main one: the
+        # host-bound 0.3 ms no longer leave the GPU idle.  Every timed step still runs one head and one body (the prefetch of the batch
+        # after the last timed step is inside the timed region; the very first head ran during warm-up).  BENCH_NO_PREFETCH=1: in line.
+        self.prefetch = os.environ.get("BENCH_NO_PREFETCH", "0") != "1"
+        self.head_stream = torch.cuda.Stream(device=device) if self.prefetch else None
+        self.next_head = None  # (feat, flen, event) of the batch the next step trains on
+
+    def _head(self):
+        with torch.no_grad():  # frontend + SpecAugment stay eager: SpecAugment's index draws read the lengths on the host
+            feat, flen = self.fe(self.wave, self.lens)
+            feat, flen = self.norm(feat, flen, epoch=1)  # module/encoder/asr.py:111-115: between the frontend and SpecAugment
+            return self.sa(feat, flen)
+
+    def _load_batch(self):
+        """Features of the batch this step trains on -> the static inputs of the captured region."""
+        main = torch.cuda.current_stream()
+        if not self.prefetch:
+            feat, flen = self._head()
+        else:
+            if self.next_head is None:  # first step: nothing was prefetched
+                with torch.cuda.stream(self.head_stream):
+                    self.head_stream.wait_stream(main)
+                    feat, flen = self._head()
+                    ev = torch.cuda.Event()
+                    ev.record(self.head_stream)
+                self.next_head = (feat, flen, ev)
+            feat, flen, ev = self.next_head
+            main.wait_event(ev)
+        with torch.no_grad():
+            self.feat.copy_(feat)
+            self.flen.copy_(flen)
+        if self.prefetch:  # the head stream may reuse the memory of (feat, flen) only after these copies have run
+            self.copied = torch.cuda.Event()
+            self.copied.record(main)
+
+    def _prefetch_next(self):
+        """Called right after this step's device work has been launched: the next batch's head, on the head stream."""
+        if not self.prefetch:
+            return
+        with torch.cuda.stream(self.head_stream):
+            self.head_stream.wait_event(self.copied)
+            feat, flen = self._head()
+            ev = torch.cuda.Event()
+            ev.record(self.head_stream)
+        self.next_head = (feat, flen, ev)
 
     # ---- the two device-side halves of a step; eager or replayed from hipGraphs --------------------------------------
     def _body(self):
@@ -294,12 +340,7 @@ class ASRTrainStepWorkload:
         self.nstep += 1
         # Noam schedule, warmup 25000 (optim_sche/noam.py:42-59): a scalar fill outside the graphs
         self.lr.fill_(2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5)
-        with torch.no_grad():  # frontend + SpecAugment stay eager: SpecAugment's index draws read the lengths on the host
-            feat, flen = self.fe(self.wave, self.lens)
-            feat, flen = self.norm(feat, flen, epoch=1)  # module/encoder/asr.py:111-115: between the frontend and SpecAugment
-            feat, flen = self.sa(feat, flen)
-            self.feat.copy_(feat)
-            self.flen.copy_(flen)
+        self._load_batch()
         graph = self.use_graph and not instrument and self.nstep > 3
         if graph and self.g_body is None:
             self._capture()
@@ -310,12 +351,14 @@ class ASRTrainStepWorkload:
                     self.reducer.launch_bucket(bi)
             self.reducer.wait()  # the optimizer's stream waits for the collectives; nothing is launched twice
             self.g_tail.replay()
+            self._prefetch_next()
             return self.loss
         if graph:
             self.g_body.replay()
             if self.reducer.multi:
                 self.reducer.reduce_all_now()
             self.g_tail.replay()
+            self._prefetch_next()
             return self.loss
         if instrument:  # HIP events around every GEMM launch of this (eager) step
             lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev, "sc_wgrad_grouped": self.ev}
@@ -344,6 +387,7 @@ class ASRTrainStepWorkload:
             lib.timing = None
             lib.flop_log = None
             lib.kernel_log = None
+        self._prefetch_next()
         return loss
 
     def roofline(self):

@@ -303,12 +303,14 @@ __device__ __forceinline__ void epilogue_tile_fused(const GemmArgs& p, const flo
         else if (ACT == ACT_GELU) v[j] *= sc_gelu_grad_t<kBf16>(aux[j]);
         else v[j] *= aux[j];  // AUX_MUL: the factor was prepared by the forward product (PREG)
       } else if (PREG && ACT == ACT_GELU) {
-        // gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x): one erf serves both
+        // gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x): one erf serves both, and the erf approximation's own exp(-(x/sqrt 2)^2) IS
+        // the Gaussian factor of phi(x)
         const float x = v[j];
-        const float e = kBf16 ? sc_erf_fast(x * 0.70710678118654752f) : sc_erf(x * 0.70710678118654752f);
+        float g;  // exp(-x^2 / 2)
+        const float e = kBf16 ? sc_erf_fast_g(x * 0.70710678118654752f, g) : sc_erf_g(x * 0.70710678118654752f, g);
         const float Phi = 0.5f * (1.f + e);
         v[j] = x * Phi;
-        pre[j] = fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), Phi);
+        pre[j] = fmaf(x * 0.39894228040143268f, g, Phi);
       } else {
         if (PREG) pre[j] = (ACT == ACT_RELU) ? (v[j] > 0.f ? 1.f : 0.f) : 1.f;
         if (ACT == ACT_RELU) v[j] = fmaxf(v[j], 0.f);

@@ -87,7 +87,7 @@ __device__ __forceinline__ bool sc_dropped(unsigned long long seed, unsigned lon
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) on v_exp/v_rcp -- ~4x cheaper than erff in a GEMM epilogue
 __device__ __forceinline__ float sc_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));  // (v_rcp_f32, 1 ulp: __frcp_rn expands to the 10-instruction IEEE division)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
@@ -98,11 +98,30 @@ __device__ __forceinline__ float sc_erf(float x) {
 // 3-term variant (A&S 7.1.25, |error| <= 2.5e-5): used where the result is rounded to bf16 (eps 3.9e-3) anyway
 __device__ __forceinline__ float sc_erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.47047f, ax, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, ax, 1.f));
   float poly = fmaf(0.7478556f, t, -0.0958798f);
   poly = fmaf(poly, t, 0.3480242f);
   const float r = 1.f - poly * t * __expf(-ax * ax);
   return copysignf(r, x);
+}
+// the same two, also handing back exp(-x^2) (for GELU': with x = u / sqrt 2 that is the Gaussian factor exp(-u^2 / 2) of phi(u))
+__device__ __forceinline__ float sc_erf_g(float x, float& gauss) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  gauss = __expf(-ax * ax);
+  return copysignf(1.f - poly * t * gauss, x);
+}
+__device__ __forceinline__ float sc_erf_fast_g(float x, float& gauss) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f, ax, 1.f));
+  float poly = fmaf(0.7478556f, t, -0.0958798f);
+  poly = fmaf(poly, t, 0.3480242f);
+  gauss = __expf(-ax * ax);
+  return copysignf(1.f - poly * t * gauss, x);
 }
 template <bool FAST>
 __device__ __forceinline__ float sc_gelu_t(float x) {
@@ -110,10 +129,13 @@ __device__ __forceinline__ float sc_gelu_t(float x) {
 }
 template <bool FAST>
 __device__ __forceinline__ float sc_gelu_grad_t(float x) {
-  const float e = FAST ? sc_erf_fast(x * 0.70710678118654752f) : sc_erf(x * 0.70710678118654752f);
-  return 0.5f * (1.f + e) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  float g;
+  const float e = FAST ? sc_erf_fast_g(x * 0.70710678118654752f, g) : sc_erf_g(x * 0.70710678118654752f, g);
+  return 0.5f * (1.f + e) + x * 0.39894228040143268f * g;
 }
 __device__ __forceinline__ float sc_gelu(float x) { return 0.5f * x * (1.f + sc_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float sc_gelu_grad(float x) {
-  return 0.5f * (1.f + sc_erf(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  float g;
+  const float e = sc_erf_g(x * 0.70710678118654752f, g);
+  return 0.5f * (1.f + e) + x * 0.39894228040143268f * g;
 }

@@ -102,6 +102,18 @@ __device__ __forceinline__ int frag_tr_offset(int rbase, int ks, int lane) {
 __device__ __forceinline__ void frag_tr_issue(unsigned addr, Frag& f) {
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr));
 }
+// s_waitcnt lgkmcnt(N) that the fragments "pass through": the compiler believes an asm read has delivered its registers when the
+// statement ends, so anything computed from them (the MFMAs, the column-sum adds) may legally be moved in front of a plain wait
+// statement -- across basic blocks too, where sched_barrier does not reach (it did: the adds common to both arms of a branch were
+// hoisted above both waits and summed stale registers).  With the registers as in/out operands of the wait, every consumer depends
+// on the wait itself.
+// Only the B fragments are tied (every MFMA of a block consumes one of them, so every MFMA depends on the wait); tying all twelve
+// fragments of the 256 x 256 kernel cost 20 VGPRs and pushed it into scratch.
+template <int N>
+__device__ __forceinline__ void frag_wait(Frag (&fb)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(fb[0].lo), "+v"(fb[0].hi), "+v"(fb[1].lo), "+v"(fb[1].hi) : [n] "n"(N));
+}
+
 __device__ __forceinline__ bf16x8_t frag_value(const Frag& f) {
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
 #define SC_CSUM_ADD()                                                                         \
   do {                                                                                        \
     if constexpr (decltype(with_csum)::value) {                                               \
-      __builtin_amdgcn_sched_barrier(0);  /* the adds consume asm outputs: they must stay behind the lgkmcnt(0) in front of them */ \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(csu[0]), "+v"(csu[1]));  /* the adds depend on this wait (see frag_wait) */ \
       _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                    \
           cs[2 * e_] += __uint_as_float(csu[i_][e_] << 16);                                   \
@@ -241,17 +253,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
         }                                                                                     \
     }                                                                                         \
   } while (0)
-// the MFMAs must not be scheduled above the wait that makes their operands valid: sched_barrier (they do not touch memory, so the
-// asm's "memory" clobber alone does not hold them)
-#define SC_MMA(FA, FB)                                                                        \
+// the MFMAs consume the outputs of the wait in front of them (frag_wait); the sched_barriers keep the block where it is: not above
+// the reads it should overlap with, not below the next barrier (that would expose the reads just issued)
+#define SC_MMA(FA, FB, NWAIT)                                                                 \
   do {                                                                                        \
+    frag_wait<NWAIT>(FB);  /* all but the NWAIT youngest LDS reads have delivered */          \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_)                                         \
       _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                        \
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(FA[i_]), frag_value(FB[j_]), acc[i_][j_], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);  /* ... nor sink below the next wait / barrier (that would expose the reads just issued) */ \
   } while (0)
-#define SC_LGKM_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
 // tile T+1 has landed for this wave; after the barrier it is visible to all, every wave holds tile T in registers, and the stage of
 // tile T is free for tile T + STAGES
 #define SC_PUBLISH_NEXT(T)                                                                    \
@@ -284,27 +296,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
     for (; t + STAGES < nk; ++t) {  // steady state, branch-free
       SC_FRAGS(t, 1, fa1, fb1);
       SC_CSUM_ISSUE(t);
-      SC_LGKM_WAIT(RPH + CSR);      // the first half's fragments (issued one half earlier) are in; this half's reads stay in flight
-      SC_MMA(fa0, fb0);
+      SC_MMA(fa0, fb0, RPH + CSR);  // the first half's fragments (issued one half earlier) are in; this half's reads stay in flight
       SC_PUBLISH_STEADY(t);         // (contains lgkmcnt(0): the second half's fragments and the column-sum reads are in)
       SC_CSUM_ADD();
       SC_FRAGS(t + 1, 0, fa0, fb0);
-      SC_MMA(fa1, fb1);
+      SC_MMA(fa1, fb1, RPH);
     }
     for (; t < nk; ++t) {
       SC_FRAGS(t, 1, fa1, fb1);
       SC_CSUM_ISSUE(t);
-      SC_LGKM_WAIT(RPH + CSR);
-      SC_MMA(fa0, fb0);
+      SC_MMA(fa0, fb0, RPH + CSR);
       if (t + 1 < nk) {
         SC_PUBLISH_NEXT(t);
         SC_CSUM_ADD();
         SC_FRAGS(t + 1, 0, fa0, fb0);
       } else {
-        SC_LGKM_WAIT(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         SC_CSUM_ADD();
       }
-      SC_MMA(fa1, fb1);
+      SC_MMA(fa1, fb1, RPH);  // (its operands were waited for in either arm; this wait only carries the dependence)
     }
   };
   if (csum) main_loop(std::true_type{});
@@ -313,7 +323,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
 #undef SC_FRAGS
 #undef SC_CSUM_ISSUE
 #undef SC_CSUM_ADD
-#undef SC_LGKM_WAIT
 #undef SC_MMA
 #undef SC_PUBLISH_NEXT
 #undef SC_PUBLISH_STEADY

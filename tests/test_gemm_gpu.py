@@ -264,7 +264,9 @@ def test_grouped_weight_gradients(tile):
         tok = dz.size(0)
         assert torch.allclose(dW.double(), ref, atol=2e-3 * math.sqrt(tok), rtol=1e-3), (dz.shape, x.shape, float((dW.double() - ref).abs().max()))
         if want_db:
-            assert torch.allclose(db.double(), dz.double().sum(0), atol=1e-3 * math.sqrt(tok), rtol=1e-4), (dz.shape, float((db.double() - dz.double().sum(0)).abs().max()))
+            err = (db.double() - dz.double().sum(0)).abs()
+            assert torch.allclose(db.double(), dz.double().sum(0), atol=1e-3 * math.sqrt(tok), rtol=1e-4), \
+                (dz.shape, float(err.max()), (err > 1e-2 * math.sqrt(tok)).nonzero().flatten().tolist()[:16])
 
 
 def test_grouped_weight_gradients_refuse_unsupported_shapes():
