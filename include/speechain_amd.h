@@ -215,6 +215,16 @@ long long sc_layernorm_bwd_workspace(long long R, int D);
 int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                      void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
                      long long ws_bytes, int stages, hipStream_t stream);
+/* sc_layernorm_bwd with a second output: dz (R, D) = dx * keepmask / (1 - drop_p), the mask of the dropout site whose output this
+ * LayerNorm normalised (stateless generator keyed (*seed, offset + r * D + c), as sc_dropout).  In a pre-LN stack the gradient a
+ * LayerNorm backward returns goes straight into the backward pass of the preceding sublayer (encoder.py:115-141), which starts by
+ * masking it; produced here, that costs one extra store instead of a launch that re-reads dx.  dz is computed from the ROUNDED dx, so
+ * it equals sc_dropout(dx) bit for bit.  bf16, D % 8 == 0, D <= 2048 only (sc_layernorm_bwd_dz_supported). */
+int sc_layernorm_bwd_dz_supported(int dtype, int D);
+int sc_layernorm_bwd_dz(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
+                        long long ws_bytes, int stages, void* dz, float drop_p, const unsigned long long* seed,
+                        unsigned long long offset, hipStream_t stream);
 int sc_layernorm_bwd_finish(int n, const void* const* workspaces, const long long* R, const int* D, float* const* dgamma,
                             float* const* dbeta, hipStream_t stream);
 

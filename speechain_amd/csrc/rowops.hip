@@ -195,8 +195,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const unsigned s
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned short* dy, const unsigned short* x, const float* mean,
                                                                 const float* rstd, const float* gamma, unsigned short* dx, float* part,
-                                                                long long R, int D, int rows_per_block, const unsigned short* dres) {
+                                                                long long R, int D, int rows_per_block, const unsigned short* dres,
+                                                                unsigned short* dz, float drop_p, const unsigned long long* seed_ptr,
+                                                                unsigned long long offset) {
   extern __shared__ float red[];  // [4 waves][2][D]
+  // optional second output: dz = dx * keepmask / (1 - p) of the dropout site whose output this LayerNorm normalised (element index =
+  // offset + row * D + column, the convention of sc_dropout): what that site's backward pass would otherwise make from dx in its own launch
+  const unsigned long long seed = dz ? *seed_ptr : 0ull;
+  const unsigned thr = sc_drop_threshold(drop_p);
+  const float keep = 1.f / (1.f - drop_p);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float gm[NV][8], dg[NV][8], db[NV][8];
 #pragma unroll
@@ -247,7 +254,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
         if (dres) ln_unpack8(*reinterpret_cast<const uint4*>(dres + base + k), rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2) + (dres ? rv[e] : 0.f);
-        *reinterpret_cast<uint4*>(dx + base + k) = ln_pack8(o);
+        const uint4 packed = ln_pack8(o);
+        *reinterpret_cast<uint4*>(dx + base + k) = packed;
+        if (dz) {  // from the ROUNDED dx, so that the result equals sc_dropout applied to the stored tensor bit for bit
+          float q[8];
+          ln_unpack8(packed, q);
+          const unsigned long long idx0 = offset + (unsigned long long)(base + k);
+          unsigned hsh = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned long long idx = idx0 + e;
+            if (e == 0 || (idx & 1) == 0) hsh = sc_rand_pair(seed, idx >> 1);
+            const bool dropped = ((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr;
+            q[e] = dropped ? 0.f : q[e] * keep;
+          }
+          *reinterpret_cast<uint4*>(dz + base + k) = ln_pack8(q);
+        }
       }
     }
   }
@@ -583,9 +605,13 @@ SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
   return blocks * 2 * D * (long long)sizeof(float);
 }
 
-SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                            void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
-                            long long ws_bytes, int stages, hipStream_t stream) {
+// 1 if sc_layernorm_bwd_dz can write its masked second output for this case (the 16-byte vector kernel: bf16, D % 8 == 0, D <= 2048)
+SC_API int sc_layernorm_bwd_dz_supported(int dtype, int D) { return dtype == 1 && D % 8 == 0 && D <= 2048; }
+
+static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
+                              long long ws_bytes, int stages, void* dz, float drop_p, const unsigned long long* seed,
+                              unsigned long long offset, hipStream_t stream) {
   SC_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "sc_layernorm_bwd: null pointer");
   SC_CHECK_ARG(stages == 1 || stages == 3, "sc_layernorm_bwd: stages is 1 (dx + partial sums; finish with sc_layernorm_bwd_finish) or 3 (everything)");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
@@ -596,13 +622,16 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
   blocks = (R + rpb - 1) / rpb;
   const size_t smem = (size_t)8 * D * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_layernorm_bwd: D too large for the LDS reduction");
-  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
+  const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dres | (uintptr_t)dz) % 16 == 0);
+  SC_CHECK_ARG(dz == nullptr || vec, "sc_layernorm_bwd_dz: the masked second output needs bf16, D %% 8 == 0, D <= 2048 and 16-byte aligned tensors");
+  SC_CHECK_ARG(dz == nullptr || (drop_p > 0.f && drop_p < 1.f && seed != nullptr && offset % 2 == 0), "sc_layernorm_bwd_dz: 0 < p < 1, a seed cell and an even offset");
   if (vec) {
     const dim3 grid((unsigned)blocks);
     const unsigned short *dy16 = (const unsigned short*)dy, *x16 = (const unsigned short*)x;
-    if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
-    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
-    else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres);
+    unsigned short* dz16 = (unsigned short*)dz;
+    if (D <= 512) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<1>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres, dz16, drop_p, seed, offset);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres, dz16, drop_p, seed, offset);
+    else hipLaunchKernelGGL(layernorm_bwd_vec_kernel<4>, grid, dim3(256), smem, stream, dy16, x16, mean, rstd, gamma, (unsigned short*)dx, (float*)workspace, R, D, rpb, (const unsigned short*)dres, dz16, drop_p, seed, offset);
   } else {
     SC_DISPATCH_TN(dtype, D, layernorm_bwd_kernel, 8, 16, 32, dim3((unsigned)blocks), dim3(256), smem, stream, dy, x, mean, rstd, gamma, dx,
                   (float*)workspace, R, D, rpb, dres);
@@ -613,6 +642,22 @@ SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const floa
     SC_LAUNCH_CHECK("reduce_parts_kernel");
   }
   return SC_OK;
+}
+
+SC_API int sc_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
+                            long long ws_bytes, int stages, hipStream_t stream) {
+  return layernorm_bwd_impl(dtype, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, R, D, dres, workspace, ws_bytes, stages, nullptr, 0.f,
+                            nullptr, 0ull, stream);
+}
+
+SC_API int sc_layernorm_bwd_dz(int dtype, const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               void* dx, float* dgamma, float* dbeta, long long R, int D, const void* dres, void* workspace,
+                               long long ws_bytes, int stages, void* dz, float drop_p, const unsigned long long* seed,
+                               unsigned long long offset, hipStream_t stream) {
+  SC_CHECK_ARG(dz, "sc_layernorm_bwd_dz: null dz");
+  return layernorm_bwd_impl(dtype, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, R, D, dres, workspace, ws_bytes, stages, dz, drop_p, seed,
+                            offset, stream);
 }
 
 // Second stage of up to LN_BATCH LayerNorm backward calls in ONE launch (grid.z = call): in a training step the 44 parameter-gradient

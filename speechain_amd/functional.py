@@ -70,6 +70,7 @@ class DropoutState:
         for c in cls.cells.values():
             c.add_(0x9E3779B97F4A7C15 - (1 << 64))  # odd constant: the int64 cell walks all 2^64 values
         cls.offset = 0
+        _MaskedGrad.sites.clear()  # (sites noted in the previous step whose output never reached a LayerNorm)
 
     @classmethod
     def reset(cls, seed: int):
@@ -309,6 +310,7 @@ class GradSinks:
         cls.step += 1
         _LnFinish.reset()  # (entries of a backward call that raised must not survive into the next step)
         _WgradQueue.reset()
+        _MaskedGrad.reset()
 
     @classmethod
     def take(cls, params: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -499,6 +501,75 @@ def _dropout_apply(x: torch.Tensor, p: float, seed: int, offset: int) -> torch.T
     return y
 
 
+class _MaskedGrad:
+    """Hands the masked gradient of a dropout site from the LayerNorm backward that produced the gradient to the site's own backward.
+
+    In a pre-LN stack y = x + dropout(sublayer(LN(x))) the gradient that arrives at a sublayer is what the NEXT LayerNorm's backward
+    kernel wrote, and the sublayer's backward starts by masking it (dz = dy * keepmask / (1 - p)) before two GEMMs consume it -- a
+    launch per sublayer that re-reads 8 MB to write 8 MB.  The LayerNorm backward kernel can write dz as a second output
+    (``sc_layernorm_bwd_dz``) if it knows the site's (p, seed, offset).  The link is made through addresses, not tensor objects
+    (views and autograd's own wrappers change those):
+      forward:   the site notes (p, seed, offset) under the address of its output; a LayerNorm whose input has a noted address
+                 remembers the site;
+      backward:  that LayerNorm writes dz next to dx and files it under dx's address, HOLDING dx -- while it is held autograd cannot
+                 add another gradient into that memory in place, so a gradient that arrives at the site with this address IS dx,
+                 unmodified; the site takes dz if address, shape and (p, seed, offset) all agree, else it masks the gradient itself.
+    Everything is dropped at the start of a step."""
+
+    enabled = _os.environ.get("SC_FUSE_DROPOUT_BWD", "1") == "1"  # (A/B knob)
+    sites = {}    # address of a site's output -> (p, seed, offset, numel)
+    ready = {}    # address of dx -> (dx, dz, (p, seed, offset))
+    armed = False
+    hits = 0      # masked gradients handed over so far (tests)
+
+    @classmethod
+    def note_site(cls, y: torch.Tensor, p: float, seed: int, off: int):
+        if cls.enabled and p > 0.0 and y.dtype == torch.bfloat16:
+            if len(cls.sites) > 4096:
+                cls.sites.clear()
+            cls.sites[y.data_ptr()] = (p, seed, off, y.numel())
+
+    @classmethod
+    def site_of(cls, x2: torch.Tensor):
+        e = cls.sites.pop(x2.data_ptr(), None) if cls.enabled else None
+        return e[:3] if e is not None and e[3] == x2.numel() else None
+
+    @classmethod
+    def put(cls, dx: torch.Tensor, dz: torch.Tensor, site):
+        cls.ready[dx.data_ptr()] = (dx, dz, site)
+        if not cls.armed:  # whatever nobody took is released when this backward call ends
+            cls.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
+
+    @classmethod
+    def _end_of_backward(cls):
+        cls.armed = False
+        cls.ready.clear()
+
+    @classmethod
+    def take(cls, dy2: torch.Tensor, p: float, seed: int, off: int) -> Optional[torch.Tensor]:
+        e = cls.ready.get(dy2.data_ptr())
+        if e is None or e[2] != (p, seed, off) or e[0].shape != dy2.shape or e[0].dtype != dy2.dtype or not dy2.is_contiguous():
+            return None
+        del cls.ready[dy2.data_ptr()]
+        cls.hits += 1
+        return e[1]
+
+    @classmethod
+    def reset(cls):
+        cls.sites.clear()
+        cls.ready.clear()
+        cls.armed = False
+
+
+def _masked_grad(dy2: torch.Tensor, p: float, seed: int, off: int) -> torch.Tensor:
+    """dz = dy * keepmask / (1 - p) of a dropout site: taken from the LayerNorm backward that already made it, or made here."""
+    if p <= 0.0:
+        return dy2
+    dz = _MaskedGrad.take(dy2, p, seed, off)
+    return dz if dz is not None else _dropout_apply(dy2, p, seed, off)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Linear:  y = dropout(x W^T + b) [+ residual]      (W may be several parameters stacked along the output dim)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -528,6 +599,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, *ws)
         ctx.bias_params = [bb for bb in bs if bb is not None]
         ctx.meta = (x.shape, drop_p, seed, off, [w.size(0) for w in ws], [bb is not None for bb in bs], residual is not None)
+        _MaskedGrad.note_site(y, drop_p, seed, off)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -541,7 +613,7 @@ class _Linear(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy if has_res else None
-        dz = _dropout_apply(dy2, drop_p, seed, off)
+        dz = _masked_grad(dy2, drop_p, seed, off)
         W = weights.fused(ws, x2.dtype)
         side = _Side(x2, wgrad_only=True)
         with side:  # parameter gradients next to the data gradient
@@ -648,6 +720,7 @@ class _FFN(torch.autograd.Function):
         ctx.save_for_backward(x2, h_pre, h, w1, w2)
         ctx.bias_params = [[b1] if b1 is not None else [], [b2] if b2 is not None else []]
         ctx.meta = (x.shape, act, p_h, s1, o1, p_res, s2, o2, b1 is not None, b2 is not None, residual is not None)
+        _MaskedGrad.note_site(y, p_res, s2, o2)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -660,7 +733,7 @@ class _FFN(torch.autograd.Function):
         dy2 = dy.reshape(M, K)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dz = _dropout_apply(dy2, p_res, s2, o2)
+        dz = _masked_grad(dy2, p_res, s2, o2)
         W1, W2 = weights.fused([w1], x2.dtype), weights.fused([w2], x2.dtype)
         side = _Side(x2, wgrad_only=True)
         with side:
@@ -758,6 +831,9 @@ class _LayerNorm(torch.autograd.Function):
         ctx.beta_param = beta
         ctx.xshape = x.shape
         ctx.with_residual = with_residual
+        # the input is the output of a dropout site (out-projection / feed-forward with residual dropout): backward also writes that
+        # site's masked gradient (see _MaskedGrad)
+        ctx.site = _MaskedGrad.site_of(x2) if lib.value("sc_layernorm_bwd_dz_supported", dcode(x2), D) else None
         if with_residual:
             return y.reshape(x.shape), x.view_as(x)
         return y.reshape(x.shape)
@@ -782,8 +858,15 @@ class _LayerNorm(torch.autograd.Function):
         db = sb if sb is not None else torch.empty(D, dtype=torch.float32, device=x2.device)
         ws = torch.empty(lib.value("sc_layernorm_bwd_workspace", R, D), dtype=torch.uint8, device=x2.device)
         batched = _LnFinish.enabled and sg is not None and sb is not None  # both outputs are bucket slots: see _LnFinish
-        lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
-                 _p(dr2), _p(ws), ws.numel(), 1 if batched else 3, stream())
+        site = ctx.site
+        if site is not None and all(t is None or t.data_ptr() % 16 == 0 for t in (dy2, x2, dx, dr2)):
+            dz = torch.empty_like(x2)
+            lib.call("sc_layernorm_bwd_dz", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
+                     _p(dr2), _p(ws), ws.numel(), 1 if batched else 3, _p(dz), float(site[0]), int(site[1]), int(site[2]), stream())
+            _MaskedGrad.put(dx, dz, site)
+        else:
+            lib.call("sc_layernorm_bwd", dcode(x2), _p(dy2), _p(x2), _p(mean), _p(rstd), _p(gamma.detach()), _p(dx), _p(dg), _p(db), R, D,
+                     _p(dr2), _p(ws), ws.numel(), 1 if batched else 3, stream())
         if batched:
             _LnFinish.add(ws, R, D, dg, db)
         return dx.reshape(ctx.xshape), dg, db, None, None

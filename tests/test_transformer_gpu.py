@@ -506,3 +506,45 @@ def test_embedding_table_gradient_vs_torch(dtype):
         assert float(got[0].abs().max()) == 0.0  # the padding row
         scale = float(table.grad.abs().max())
         assert torch.allclose(got, table.grad, atol=(1e-5 if dtype == torch.float32 else 2e-2) * scale, rtol=1e-5), float((got - table.grad).abs().max())
+
+
+def test_masked_gradient_from_layernorm_backward_equals_the_separate_dropout_launch():
+    """In a pre-LN stack the LayerNorm backward kernel also writes the masked gradient of the dropout site in front of it
+    (sc_layernorm_bwd_dz, functional._MaskedGrad) instead of the site re-reading dx in a launch of its own.  Same generator, same
+    offsets, dz formed from the rounded dx: every gradient of a 3-layer encoder must come out BIT FOR BIT as with the hand-over off."""
+    from speechain_amd.module.transformer.encoder import TransformerEncoder
+
+    def run(fused: bool):
+        torch.manual_seed(0)
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.DropoutState.reset(1234)
+        Fn.weights.invalidate()
+        Fn._MaskedGrad.reset()
+        Fn._MaskedGrad.enabled = fused
+        hits0 = Fn._MaskedGrad.hits
+        enc = TransformerEncoder(input_size=64, d_model=64, num_heads=4, num_layers=3, fdfwd_dim=128, posenc_dropout=0.2, att_dropout=0.2,
+                                 fdfwd_dropout=0.2, res_dropout=0.2, layernorm_first=True).cuda().train()
+        for p in enc.parameters():
+            if p.dim() == 1:
+                torch.nn.init.normal_(p, std=0.3)
+        x = torch.randn(3, 40, 64, device="cuda", requires_grad=True)
+        mask = torch.ones(3, 1, 40, dtype=torch.bool, device="cuda")
+        mask[1, :, 31:] = False
+        out = enc(x, mask)[0]
+        (out.float() * torch.linspace(-1, 1, 64, device="cuda")).sum().backward()
+        grads = {k: p.grad.detach().clone() for k, p in enc.named_parameters() if p.grad is not None}
+        grads["input"] = x.grad.detach().clone()
+        return grads, Fn._MaskedGrad.hits - hits0
+
+    try:
+        g_off, hits_off = run(False)
+        g_on, hits_on = run(True)
+    finally:
+        Fn.set_compute_dtype(None)
+        Fn._MaskedGrad.enabled = True
+        Fn.weights.invalidate()
+    assert hits_off == 0
+    assert hits_on >= 5, hits_on  # 3 layers x 2 sites, all but the last feed-forward's... every site whose output feeds a LayerNorm
+    assert g_on.keys() == g_off.keys()
+    for k in g_on:
+        assert torch.equal(g_on[k], g_off[k]), (k, float((g_on[k].float() - g_off[k].float()).abs().max()))
