@@ -760,8 +760,12 @@ typedef __attribute__((address_space(3))) void* sc_lptr_t;
 //   2  software-pipelined by whole tiles: tile t+1's fragments are read while tile t is multiplied (4 x (MI + 2) fragments)
 // In 1 and 2 the barrier of iteration t publishes tile t+1 (not t), all waves have tile t in registers by then, so the stage of
 // tile t is free and receives tile t + STAGES: STAGES - 1 tiles in flight behind the one being read.
-template <int WM, int WN, int MI, int PF>
+// KTAIL (PF 0 only): K is a multiple of 8 but not of 32 (the 5000-wide contraction of the vocabulary heads' data gradients).  The last
+// K tile is partial: lanes whose 16-byte source chunk lies beyond K read chunk 0 of that tile instead (valid memory), and the fragments
+// of the k-chunks beyond K are zeroed in registers before they reach the matrix cores.
+template <int WM, int WN, int MI, int PF, bool KTAIL = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf16_nt_dma_kernel(GemmArgs p) {
+  static_assert(!KTAIL || PF == 0, "the K tail is implemented in the unpipelined loop only");
   constexpr int NW = WM * WN, TM = WM * MI * 32, TN = WN * 64;
   constexpr int STAGES = 4, STAGE_ELEMS = (TM + TN) * BK16;
   constexpr int ACH = TM / 16 / NW, BCH = TN / 16 / NW;  // 1 KB chunks (16 rows) of A / B each wave stages per tile
@@ -811,14 +815,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK16;
+  const int nk = KTAIL ? (p.K + BK16 - 1) / BK16 : p.K / BK16;
+  const int ktail = KTAIL ? p.K % BK16 : 0;  // (8, 16 or 24 when KTAIL)
+  // source chunk of this lane inside a K tile ((row >> 2) & 3 == (lane >> 4) & 3 for every chunk row of every wave) and how far to step
+  // back in the last tile when that chunk lies beyond K
+  const int tail_adj = (KTAIL && (((lane & 3) ^ ((lane >> 4) & 3)) * 8 >= ktail)) ? ((lane & 3) ^ ((lane >> 4) & 3)) * 8 : 0;
 #define SC_DMA_ISSUE(T)                                                                                                \
   do {                                                                                                                 \
     unsigned short* st_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                                                        \
+    const int koff_ = (T) * BK16 - ((KTAIL && (T) == nk - 1) ? tail_adj : 0);                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < ACH; ++i_)                                                                 \
-      __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + (T) * BK16), (sc_lptr_t)(st_ + (wid + NW * i_) * 512), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + koff_), (sc_lptr_t)(st_ + (wid + NW * i_) * 512), 16, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < BCH; ++i_)                                                                 \
-      __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + (T) * BK16),                                             \
+      __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + koff_),                                                  \
                                        (sc_lptr_t)(st_ + TM * BK16 + (wid + NW * i_) * 512), 16, 0, 0);                \
   } while (0)
 
@@ -899,6 +908,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
       for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(as + aoff[i][ks]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8_t*)(bs + boff[j][ks]);
+      if (KTAIL && t == nk - 1 && (2 * ks + h) * 8 >= ktail) {  // this lane's k-chunk of the partial tile lies beyond K
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[i][e] = (__bf16)0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b[j][e] = (__bf16)0.f;
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -976,7 +995,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become epilogue staging
 
-  epilogue_wave_fused<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
+  if constexpr (KTAIL)  // (data gradients: plain / bias / run-time general epilogue; keeps the number of instantiations down)
+    epilogue_wave<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
+  else
+    epilogue_wave_fused<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1233,12 +1255,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
   }
 }
 
-template <int WM, int WN, int MI, int PF>
+template <int WM, int WN, int MI, int PF, bool KTAIL = false>
 int launch_dma_pf(const GemmArgs& a, int nbatch, hipStream_t stream) {
   constexpr int TM = WM * MI * 32, TN = WN * 64;
   constexpr size_t smem = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short);
   static_assert(smem >= (size_t)WM * WN * 32 * STG_LD * sizeof(float), "operand stages must cover the epilogue staging");
-  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF>;
+  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF, KTAIL>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return sc_set_error(SC_ERR_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1257,6 +1279,7 @@ int launch_dma_pf(const GemmArgs& a, int nbatch, hipStream_t stream) {
 //           26.4 us for PF 0 / 1 / 2; 8192^3: 1182 / 1353 / 1265 us)
 template <int WM, int WN, int MI, int PF>
 int launch_dma(const GemmArgs& a, int nbatch, hipStream_t stream) {
+  if (a.K % BK16 != 0) return launch_dma_pf<WM, WN, MI, 0, true>(a, nbatch, stream);  // partial last K tile
   return launch_dma_pf<WM, WN, MI, PF>(a, nbatch, stream);
 }
 
@@ -1487,7 +1510,7 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   }
   const int nb = nb1 * nb2;
   if (dtype == 1) {
-    if (!ta && !tb && a.a_vec && a.b_vec && (K % BK16 == 0) && K >= 2 * BK16) {
+    if (!ta && !tb && a.a_vec && a.b_vec && (K % 8 == 0) && K >= 2 * BK16) {
       // 256 x 256 tiles when they still give every CU work, else 128 x 128
       const long long big = (long long)sc_cdiv(M, 256) * sc_cdiv(N, 256) * nb;
       // Few 128 x 128 tiles (the decoder-sized products, M ~ 2000: 64 .. 192 workgroups on 256 CUs): 64 x 128 tiles double the

@@ -278,3 +278,24 @@ def test_grouped_weight_gradients_refuse_unsupported_shapes():
     assert lib.value("sc_wgrad_grouped_supported", 512, 512, 64, 500, 512) == 0    # row stride below the width
     with pytest.raises(RuntimeError, match="not supported"):
         _grouped([(_mk((100, 64), torch.bfloat16, 1), _mk((100, 64), torch.bfloat16, 2), False)], 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (996, 512, 5000), (2016, 512, 200), (129, 264, 104), (7968, 520, 88)])
+def test_partial_last_k_tile_on_the_dma_kernels(M, N, K):
+    """K a multiple of 8 but not of 32 (the 5000-wide contraction of the vocabulary heads' data gradients) stays on the LDS-DMA kernels:
+    out-of-range source chunks of the last K tile are redirected, their fragments zeroed.  Operands carry NaN / Inf right behind the
+    valid columns of a wider buffer, so anything read from beyond K and not zeroed would poison the result."""
+    from speechain_amd._lib import lib
+
+    Aw = torch.full((M, K + 40), float("nan"), dtype=torch.bfloat16, device="cuda")
+    Bw = torch.full((N, K + 40), float("inf"), dtype=torch.bfloat16, device="cuda")
+    Aw[:, :K] = _mk((M, K), torch.bfloat16, 21)
+    Bw[:, :K] = _mk((N, K), torch.bfloat16, 22)
+    A, B = Aw[:, :K], Bw[:, :K]
+    bias = _mk((N,), torch.float32, 23)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    Fn.gemm(Fn.BF16, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, A.stride(0), B.stride(0), N, bias=bias)
+    assert "nt_dma" in lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode()
+    ref = A.double() @ B.double().t() + bias.double()
+    assert torch.isfinite(C.float()).all()
+    assert torch.allclose(C.double(), ref, **_tol(torch.bfloat16, K)), float((C.double() - ref).abs().max())
