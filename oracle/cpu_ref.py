@@ -724,3 +724,132 @@ def conv2d_prenet(feat: Tensor, feat_len: Tensor, P: Dict[str, Tensor], prefix: 
                 x = _activation(lnr_activation)(x)
                 pos += 1
     return x, feat_len, stats
+
+
+# --------------------------------------------------------------------------------------------------
+# f4  FastSpeech2 glue (BASELINE configs[4])
+#     prenet/conv1d.py:20-128 (Conv1dEv), prenet/var_pred.py:42-233, postnet/conv1d.py:16-166, prenet/embed.py:13-66,
+#     encoder/tts.py:20-86, decoder/nar_tts.py:21-502, criterion/least_error.py:15-129, model/nar_tts.py:472-560
+# --------------------------------------------------------------------------------------------------
+
+def conv1d_same(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """Conv1dEv(padding_mode='same', stride 1, odd kernel) on a (B, T, C) tensor (prenet/conv1d.py:79-86, 120-128)."""
+    assert w.size(-1) % 2 == 1
+    return F.conv1d(x.transpose(1, 2), w, b, padding=(w.size(-1) - 1) // 2).transpose(1, 2)
+
+
+def var_predictor(x: Tensor, P: Dict[str, Tensor], prefix: str, num_layers: int) -> Tensor:
+    """Conv1dVarPredictor.forward, dropout off (var_pred.py:185-215): [Conv1dEv -> ReLU -> LayerNorm over channels, eps 1e-12
+    (:9-39, :141-160) -> Dropout] x num_layers, then Linear(C, 1) squeezed.  The Sequential holds 4 entries per block."""
+    for i in range(num_layers):
+        x = torch.relu(conv1d_same(x, P[f"{prefix}conv.{4 * i}.conv_lyr.weight"], P[f"{prefix}conv.{4 * i}.conv_lyr.bias"]))
+        x = F.layer_norm(x, (x.size(-1),), P[f"{prefix}conv.{4 * i + 2}.weight"], P[f"{prefix}conv.{4 * i + 2}.bias"], 1e-12)
+    return F.linear(x, P[prefix + "linear.weight"], P[prefix + "linear.bias"]).squeeze(-1)
+
+
+def var_embed(scalar: Tensor, P: Dict[str, Tensor], prefix: str) -> Tensor:
+    """Conv1dVarPredictor.emb_pred_scalar (var_pred.py:217-233): (B, T) -> (B, T, d) through Conv1dEv(1, d, conv_emb_kernel)."""
+    return conv1d_same(scalar.unsqueeze(-1), P[prefix + "conv_emb.0.conv_lyr.weight"], P[prefix + "conv_emb.0.conv_lyr.bias"])
+
+
+def conv1d_postnet(x: Tensor, P: Dict[str, Tensor], prefix: str, num_layers: int, training: bool, activation: str = "Tanh",
+                   momentum: float = 0.1, eps: float = 1e-5) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """Conv1dPostnet.forward, dropout off (postnet/conv1d.py:146-166): [Conv1dEv without bias -> BatchNorm1d -> activation -> Dropout] per
+    block over the WHOLE padded (B, T) grid (no length masking in the reference); 4 Sequential entries per block.  Returns the
+    output and the running statistics after this call (nn.BatchNorm1d: momentum 0.1, unbiased running variance)."""
+    stats = {}
+    act = _activation(activation)
+    for i in range(num_layers):
+        x = conv1d_same(x, P[f"{prefix}conv.{4 * i}.conv_lyr.weight"], None)
+        rm, rv = P[f"{prefix}conv.{4 * i + 1}.running_mean"].clone(), P[f"{prefix}conv.{4 * i + 1}.running_var"].clone()
+        x = F.batch_norm(x.transpose(1, 2), rm, rv, P[f"{prefix}conv.{4 * i + 1}.weight"], P[f"{prefix}conv.{4 * i + 1}.bias"], training,
+                         momentum, eps).transpose(1, 2)
+        stats[f"{prefix}conv.{4 * i + 1}.running_mean"], stats[f"{prefix}conv.{4 * i + 1}.running_var"] = rm, rv
+        x = act(x)
+    return x, stats
+
+
+def average_scalar_by_duration(frame_scalar: Tensor, duration: Tensor) -> Tensor:
+    """FastSpeech2Decoder.average_scalar_by_duration (decoder/nar_tts.py:150-204): token k averages the frames [sum(d[:k]), sum(d[:k+1]))
+    that exist (frames beyond the tensor are not counted); no frames -> 0 (the 1e-10 in the denominator)."""
+    B, T = frame_scalar.shape
+    end = torch.cumsum(duration, dim=1)
+    start = end - duration
+    t = torch.arange(T)[None, None, :]
+    m = (t >= start.unsqueeze(-1)) & (t < end.unsqueeze(-1))
+    return (frame_scalar.unsqueeze(1) * m).sum(-1) / (m.sum(-1) + 1e-10)
+
+
+def proc_duration(duration: Tensor, min_frame_num: int = 0, max_frame_num: Optional[int] = None, reduction_factor: int = 1) -> Tensor:
+    """FastSpeech2Decoder.proc_duration in training mode (decoder/nar_tts.py:206-230)."""
+    duration = torch.clamp(torch.round(duration), min=0)
+    zero = duration == 0
+    duration = torch.clamp(duration, min=round(min_frame_num / reduction_factor),
+                           max=None if max_frame_num is None else round(max_frame_num / reduction_factor))
+    return torch.where(zero, torch.zeros_like(duration), duration)
+
+
+def length_regulate(enc_text: Tensor, used_duration: Tensor, out_len: Tensor) -> Tensor:
+    """The expansion loop of FastSpeech2Decoder.forward (decoder/nar_tts.py:439-472): row k of utterance i repeated used_duration[i][k]
+    times, then zero-padded / cut to max(out_len)."""
+    Tm = int(out_len.max())
+    rows = []
+    for i in range(enc_text.size(0)):
+        e = enc_text[i].repeat_interleave(used_duration[i].long(), dim=0)
+        if e.size(0) < Tm:
+            e = F.pad(e, (0, 0, 0, Tm - e.size(0)))
+        rows.append(e[:Tm])
+    return torch.stack(rows)
+
+
+def least_error(pred: Tensor, tgt: Tensor, tgt_len: Tensor, loss_type: str = "L2", is_normalized: bool = True) -> Tensor:
+    """LeastError.__call__ (criterion/least_error.py:66-124)."""
+    if pred.dim() == 2:
+        pred = pred.unsqueeze(-1)
+    if tgt.dim() == 2:
+        tgt = tgt.unsqueeze(-1)
+    mask = make_mask_from_len(tgt_len, max_len=pred.size(1), return_3d=False)
+    d = pred - tgt
+    loss = {"L1": d.abs(), "L2": d * d, "L1+L2": d.abs() + d * d}[loss_type].mean(dim=-1)
+    loss = loss.masked_fill(~mask, 0.0)
+    return loss.sum() / mask.sum() if is_normalized else loss.sum(dim=-1).mean()
+
+
+def fastspeech2_forward_loss(text: Tensor, text_len: Tensor, duration: Tensor, wave: Tensor, wave_len: Tensor, pitch: Tensor,
+                             pitch_len: Tensor, P: Dict[str, Tensor], cfg: Dict, norms: Dict[str, "FeatureNormalization"], epoch: int = 1,
+                             training: bool = True):
+    """TTSEncoder.forward (encoder/tts.py:66-86) -> FastSpeech2Decoder.forward in training mode with ground-truth duration / pitch /
+    energy (decoder/nar_tts.py:232-502, reduction_factor 1, no speaker embedding) -> the loss of FastSpeech2.criterion_forward
+    (model/nar_tts.py:472-560).  `P` holds 'encoder.*' / 'decoder.*' state-dict entries, `norms` the three stateful normalisations
+    ('feat', 'pitch', 'energy').  Returns a dict of outputs, loss terms and the BatchNorm running statistics after the call."""
+    d, H, L = cfg["d"], cfg["heads"], cfg["layers"]
+    trf = dict(num_layers=L, num_heads=H, d_model=d, emb_scale=False, activation="ReLU", fdfwd_type="conv", layernorm_first=True)
+    emb = F.embedding(text, P["encoder.embedding.embed.weight"], padding_idx=0)
+    e_mask = make_mask_from_len(text_len, max_len=text.size(1))
+    enc_text, e_mask, _, _ = transformer_encoder(emb, e_mask, P, "encoder.encoder.", **trf)
+    # acoustic targets: frontend with energy (nar_tts.py:275-278), then the three normalisations (:280-283, :300-303, :320-323)
+    feat, feat_len, energy, energy_len = speech2mel(wave.squeeze(-1), wave_len, sr=22050, mag_spec=True, hop_length=256, win_length=1024, n_mels=80,
+                                                    fmin=0, fmax=8000, log_base=None, clamp=1e-5, return_energy=True)
+    feat, feat_len = norms["feat"](feat, feat_len, epoch=epoch)
+    pitch, pitch_len = norms["pitch"](pitch, pitch_len, epoch=epoch)
+    energy, energy_len = norms["energy"](energy, energy_len, epoch=epoch)
+    dp = "decoder."
+    pred_dur = var_predictor(enc_text, P, dp + "duration_predictor.", cfg["dur_layers"])
+    used = proc_duration(duration / duration.sum(dim=-1, keepdim=True) * feat_len.unsqueeze(-1))
+    pred_pitch = var_predictor(enc_text, P, dp + "pitch_predictor.", cfg["pitch_layers"])
+    tok_pitch = average_scalar_by_duration(pitch, used)
+    pred_energy = var_predictor(enc_text, P, dp + "energy_predictor.", cfg["energy_layers"])
+    tok_energy = average_scalar_by_duration(energy, used)
+    x = enc_text + var_embed(tok_pitch, P, dp + "pitch_predictor.") + var_embed(tok_energy, P, dp + "energy_predictor.")
+    x = length_regulate(x, used, feat_len)
+    dec, dmask, _, _ = transformer_encoder(x, make_mask_from_len(feat_len), P, dp + "decoder.", **trf)
+    before = F.linear(dec, P[dp + "feat_pred.weight"], P[dp + "feat_pred.bias"])
+    post, bn_stats = conv1d_postnet(before, P, dp + "postnet.", cfg["post_layers"], training)
+    after = before + post
+    terms = dict(feat_before=least_error(before, feat, feat_len, "L1"), feat_after=least_error(after, feat, feat_len, "L1"),
+                 pitch=least_error(pred_pitch, tok_pitch, text_len, "L2"), energy=least_error(pred_energy, tok_energy, text_len, "L2"),
+                 duration=least_error(pred_dur, torch.log(used.float() + 1), text_len, "L2"))
+    out = dict(enc_text=enc_text, before=before, after=after, tgt_feat=feat, tgt_feat_len=feat_len, pred_pitch=pred_pitch, tgt_pitch=tok_pitch,
+               pred_energy=pred_energy, tgt_energy=tok_energy, pred_dur=pred_dur, used_dur=used, loss=sum(terms.values()), bn_stats=bn_stats)
+    out.update({"loss_" + k: v for k, v in terms.items()})
+    return out

@@ -518,6 +518,120 @@ def g9_prenet():
         out[f"{tag}.out_eval"] = ye
     save("g9_prenet", **out)
 
+# ---- G10 FastSpeech2 (BASELINE configs[4]) ---------------------------------------------------------------
+
+TTS_SMALL = dict(d=32, heads=2, layers=2, ffn=64, pred=16, post=16, vocab=20)
+
+
+def tts_confs(c=TTS_SMALL, dropout=0.0):
+    trf = dict(posenc_dropout=dropout, posenc_scale=True, emb_scale=False, emb_layernorm=True, d_model=c["d"], num_heads=c["heads"],
+               num_layers=c["layers"], att_dropout=dropout, fdfwd_dim=c["ffn"], fdfwd_type="conv", fdfwd_args=dict(kernel_size=3),
+               fdfwd_dropout=dropout, res_dropout=dropout, layernorm_first=True, posenc_maxlen=400)
+    enc = dict(vocab_size=c["vocab"], embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=c["d"])),
+               encoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)))
+    dec = dict(
+        decoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)),
+        postnet=dict(type="postnet.conv1d.Conv1dPostnet", conf=dict(conv_dims=[c["post"], -1, 0], conv_kernel=5, conv_batchnorm=True,
+                                                                     conv_activation="Tanh", conv_dropout=dropout)),
+        pitch_predictor=dict(type="prenet.var_pred.Conv1dVarPredictor", conf=dict(conv_dims=[c["pred"], -1, -1], conv_kernel=5, conv_dropout=dropout,
+                                                                                 conv_emb_kernel=1, conv_emb_dropout=0.0)),
+        energy_predictor=dict(type="prenet.var_pred.Conv1dVarPredictor", conf=dict(conv_dims=[c["pred"], -1], conv_kernel=3, conv_dropout=dropout,
+                                                                                  conv_emb_kernel=1, conv_emb_dropout=0.0)),
+        duration_predictor=dict(type="prenet.var_pred.Conv1dVarPredictor", conf=dict(conv_dims=[c["pred"], -1], conv_kernel=3, conv_dropout=dropout)),
+        feat_frontend=dict(type="frontend.speech2mel.Speech2MelSpec", conf=dict(sr=22050, mag_spec=True, hop_length=256, win_length=1024, n_mels=80,
+                                                                                fmin=0, fmax=8000, log_base=None, clamp=1e-5)),
+        feat_normalize=True, pitch_normalize=True, energy_normalize=True)
+    return enc, dec
+
+
+def g10_tts():
+    """FastSpeech2 (recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml at small sizes): TTSEncoder (module/encoder/tts.py) ->
+    FastSpeech2Decoder (module/decoder/nar_tts.py: variance predictors, duration handling, average_scalar_by_duration, length
+    regulation, decoder stack, feat_pred, Conv1dPostnet) -> the five LeastError terms of model/nar_tts.py:472-560.  Training mode, all
+    dropout rates 0, two consecutive steps (BatchNorm running statistics, the global feature / pitch / energy normalisation buffers)."""
+    import copy
+
+    from speechain.criterion.least_error import LeastError
+    from speechain.module.decoder.nar_tts import FastSpeech2Decoder
+    from speechain.module.encoder.tts import TTSEncoder
+
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        gen = torch.Generator().manual_seed(1010)
+        ec, dc = tts_confs()
+        enc = TTSEncoder(**copy.deepcopy(ec))
+        dec = FastSpeech2Decoder(input_size=TTS_SMALL["d"], **copy.deepcopy(dc))
+        P = {}
+        for name, mod, seed in (("encoder", enc, 101), ("decoder", dec, 102)):
+            sd = seeded_state(mod, seed)
+            mod.train()
+            for k, v in sd.items():
+                P[f"{name}.{k}"] = v
+        out = {f"sd0.{k}": v for k, v in P.items() if not k.endswith("posenc.posenc") and "mel_fbanks" not in k and "preemph" not in k}
+        B, L = 3, 7
+        text_len = torch.tensor([7, 6, 4])
+        wave_len = torch.tensor([14000, 11000, 8200])
+        for step in range(2):
+            text = torch.randint(1, TTS_SMALL["vocab"], (B, L), generator=gen)
+            dur = (torch.rand(B, L, generator=gen) * 0.2 + 0.02).half().float()
+            for i in range(B):
+                text[i, text_len[i]:] = 0
+                dur[i, text_len[i]:] = 0
+            dur[1, 2] = 0.0  # a token without frames
+            wave = (torch.randn(B, int(wave_len.max()), 1, generator=gen) * 0.1).half().float()
+            for i in range(B):
+                wave[i, wave_len[i]:] = 0
+            T = int(wave_len.max()) // 256 + 1
+            pitch = (torch.rand(B, T, generator=gen) * 200 + 80).half().float()
+            pitch_len = wave_len // 256 + 1
+            for i in range(B):
+                pitch[i, pitch_len[i]:] = 0
+            e_text, e_mask, _, _ = enc(text=text.clone(), text_len=text_len.clone())
+            r = dec(enc_text=e_text, enc_text_mask=e_mask, duration=dur.clone(), duration_len=text_len.clone(), pitch=pitch.clone(),
+                    pitch_len=pitch_len.clone(), feat=wave.clone(), feat_len=wave_len.clone(), epoch=1, min_frame_num=0)  # (model/nar_tts.py:256: 0)
+            (before, after, pred_len, tgt_feat, tgt_feat_len, pred_pitch, tgt_pitch, tgt_pitch_len, pred_energy, tgt_energy, tgt_energy_len,
+             pred_dur, pred_gate, used_dur, used_dur_len, _, _) = r
+            assert pred_gate is None
+            l1, l2 = LeastError(loss_type="L1"), LeastError(loss_type="L2")
+            terms = dict(feat_before=l1(pred=before, tgt=tgt_feat, tgt_len=tgt_feat_len), feat_after=l1(pred=after, tgt=tgt_feat, tgt_len=tgt_feat_len),
+                         pitch=l2(pred=pred_pitch, tgt=tgt_pitch, tgt_len=tgt_pitch_len), energy=l2(pred=pred_energy, tgt=tgt_energy, tgt_len=tgt_energy_len),
+                         duration=l2(pred=pred_dur, tgt=torch.log(used_dur.float() + 1), tgt_len=used_dur_len))
+            loss = sum(terms.values())
+            sel = {"g_emb": enc.embedding.embed.weight, "g_enc0_ffn_in": enc.encoder.trfm_layers[0].feed_forward.in_layer.conv_lyr.weight,
+                   "g_dur_conv0": dec.duration_predictor.conv[0].conv_lyr.weight, "g_dur_ln0": dec.duration_predictor.conv[2].weight,
+                   "g_dur_lin": dec.duration_predictor.linear.weight, "g_pitch_emb_w": dec.pitch_predictor.conv_emb[0].conv_lyr.weight,
+                   "g_pitch_emb_b": dec.pitch_predictor.conv_emb[0].conv_lyr.bias, "g_energy_conv1": dec.energy_predictor.conv[4].conv_lyr.weight,
+                   "g_dec1_q": dec.decoder.trfm_layers[1].multihead_att.q_layer.weight, "g_dec_alpha": dec.decoder.posenc.alpha,
+                   "g_feat_pred": dec.feat_pred.weight, "g_post0": dec.postnet.conv[0].conv_lyr.weight, "g_post_bn1_w": dec.postnet.conv[1].weight,
+                   "g_post_last": dec.postnet.conv[8].conv_lyr.weight, "g_post_bn_last_b": dec.postnet.conv[9].bias}
+            grads = torch.autograd.grad(loss, list(sel.values()))
+            tag = f"s{step}."
+            out.update({tag + "text": text, tag + "dur": dur, tag + "wave": wave, tag + "pitch": pitch, tag + "enc_text": e_text,
+                        tag + "before": before, tag + "after": after, tag + "pred_len": pred_len, tag + "tgt_feat": tgt_feat,
+                        tag + "tgt_feat_len": tgt_feat_len, tag + "pred_pitch": pred_pitch, tag + "tgt_pitch": tgt_pitch,
+                        tag + "pred_energy": pred_energy, tag + "tgt_energy": tgt_energy, tag + "pred_dur": pred_dur, tag + "used_dur": used_dur,
+                        tag + "loss": loss})
+            out.update({tag + "loss_" + k: v for k, v in terms.items()})
+            out.update({tag + k: v for k, v in zip(sel.keys(), grads)})
+            if step == 0:  # a plain SGD move between the two steps, so that the second step sees other weights
+                with torch.no_grad():
+                    for prm, gr in zip(sel.values(), grads):
+                        prm -= 0.05 * gr
+        out["text_len"], out["wave_len"], out["pitch_len"] = text_len, wave_len, pitch_len
+        for name, mod in (("encoder", enc), ("decoder", dec)):
+            for k, v in mod.named_buffers():
+                if not k.endswith("posenc.posenc") and "mel_fbanks" not in k and "preemph" not in k:
+                    out[f"buf1.{name}.{k}"] = v.clone().float() if v.dtype.is_floating_point else v.clone()
+        # the two stand-alone helpers on their own data (tokens without frames, durations overshooting the frames)
+        fs = torch.randn(2, 11, generator=gen)
+        du = torch.tensor([[3.0, 0.0, 4.0, 2.0, 5.0], [1.0, 1.0, 0.0, 0.0, 0.0]])
+        ts, _ = FastSpeech2Decoder.average_scalar_by_duration(fs, du, torch.tensor([5, 2]))
+        out.update(avg_frame=fs, avg_dur=du, avg_out=ts)
+        save("g10_tts", **out)
+    finally:
+        torch.Tensor.cuda = real_cuda
+
 
 if __name__ == "__main__":
     only = sys.argv[1:]
@@ -534,3 +648,4 @@ if __name__ == "__main__":
     g7_harness()
     g8_featnorm()
     g9_prenet()
+    g10_tts()

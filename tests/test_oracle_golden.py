@@ -308,3 +308,64 @@ def test_conv2d_prenet_oracle_length_check():
     P = {"conv.0.weight": torch.zeros(4, 1, 3, 3), "conv.0.bias": torch.zeros(4)}
     with pytest.raises(RuntimeError, match="feature lengths"):
         R.conv2d_prenet(torch.zeros(2, 37, 20), torch.tensor([37, 30]), P, "", conv_dims=[4], conv_padding=1, lnr_dims=None)
+
+
+# ---- G10 FastSpeech2 (BASELINE configs[4]) ----------------------------------------------------------------------
+
+TTS_SMALL_CFG = dict(d=32, heads=2, layers=2, dur_layers=2, pitch_layers=3, energy_layers=2, post_layers=3)
+
+
+def tts_state(g, prefix="sd0."):
+    P = {k[len(prefix):]: v.clone() for k, v in g.items() if k.startswith(prefix)}
+    for key, d in (("encoder.encoder.posenc.posenc", 32), ("decoder.decoder.posenc.posenc", 32)):
+        P[key] = R.posenc_table(400, d)
+    return P
+
+
+def test_fastspeech2_oracle_matches_reference(golden):
+    """oracle.fastspeech2_forward_loss against the imported reference (TTSEncoder + FastSpeech2Decoder + LeastError terms, two training
+    steps with a weight update in between): every output, the five loss terms, fifteen gradients spread over all sub-modules, and the
+    buffers after the second step (BatchNorm running statistics, global feature / pitch / energy statistics)."""
+    g = golden("g10_tts")
+    P = tts_state(g)
+    norms = {k: R.FeatureNormalization() for k in ("feat", "pitch", "energy")}
+    sel = {"g_emb": "encoder.embedding.embed.weight", "g_enc0_ffn_in": "encoder.encoder.trfm_layers.0.feed_forward.in_layer.conv_lyr.weight",
+           "g_dur_conv0": "decoder.duration_predictor.conv.0.conv_lyr.weight", "g_dur_ln0": "decoder.duration_predictor.conv.2.weight",
+           "g_dur_lin": "decoder.duration_predictor.linear.weight", "g_pitch_emb_w": "decoder.pitch_predictor.conv_emb.0.conv_lyr.weight",
+           "g_pitch_emb_b": "decoder.pitch_predictor.conv_emb.0.conv_lyr.bias", "g_energy_conv1": "decoder.energy_predictor.conv.4.conv_lyr.weight",
+           "g_dec1_q": "decoder.decoder.trfm_layers.1.multihead_att.q_layer.weight", "g_dec_alpha": "decoder.decoder.posenc.alpha",
+           "g_feat_pred": "decoder.feat_pred.weight", "g_post0": "decoder.postnet.conv.0.conv_lyr.weight",
+           "g_post_bn1_w": "decoder.postnet.conv.1.weight", "g_post_last": "decoder.postnet.conv.8.conv_lyr.weight",
+           "g_post_bn_last_b": "decoder.postnet.conv.9.bias"}
+    for k in sel.values():
+        P[k] = P[k].clone().requires_grad_()
+    for step in range(2):
+        t = f"s{step}."
+        out = R.fastspeech2_forward_loss(g[t + "text"], g["text_len"], g[t + "dur"], g[t + "wave"], g["wave_len"], g[t + "pitch"], g["pitch_len"],
+                                         P, TTS_SMALL_CFG, norms, epoch=1)
+        assert torch.equal(out["tgt_feat_len"], g[t + "tgt_feat_len"]) and torch.equal(out["used_dur"], g[t + "used_dur"])
+        for k in ("enc_text", "before", "after", "tgt_feat", "pred_pitch", "tgt_pitch", "pred_energy", "tgt_energy", "pred_dur"):
+            assert torch.allclose(out[k], g[t + k], atol=2e-4, rtol=1e-4), (step, k, float((out[k] - g[t + k]).abs().max()))
+        for k in ("feat_before", "feat_after", "pitch", "energy", "duration"):
+            assert abs(float(out["loss_" + k]) - float(g[t + "loss_" + k])) < 1e-5 * max(1.0, abs(float(g[t + "loss_" + k]))), (step, k)
+        grads = torch.autograd.grad(out["loss"], [P[k] for k in sel.values()])
+        for (name, key), gr in zip(sel.items(), grads):
+            ref = g[t + name]
+            assert torch.allclose(gr, ref, atol=2e-5 + 1e-4 * float(ref.abs().max()), rtol=1e-3), (step, name, float((gr - ref).abs().max()))
+        for k, v in out["bn_stats"].items():  # running statistics carry over to the next step
+            P[k] = v
+        if step == 0:
+            with torch.no_grad():
+                for key, gr in zip(sel.values(), grads):
+                    P[key] -= 0.05 * gr
+    for k, v in out["bn_stats"].items():
+        assert torch.allclose(v, g["buf1." + k], atol=1e-5, rtol=1e-4), k
+    for tag, name in (("feat", "decoder.feat_normalize"), ("pitch", "decoder.pitch_normalize"), ("energy", "decoder.energy_normalize")):
+        for bk, bv in norms[tag].buffers.items():
+            ref = g[f"buf1.{name}.{bk}"]
+            assert torch.allclose(bv.float().reshape(-1), ref.float().reshape(-1), atol=1e-5, rtol=1e-4), (name, bk)
+
+
+def test_average_scalar_by_duration_oracle(golden):
+    g = golden("g10_tts")
+    assert torch.allclose(R.average_scalar_by_duration(g["avg_frame"], g["avg_dur"]), g["avg_out"], atol=1e-6)
