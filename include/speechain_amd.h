@@ -87,7 +87,8 @@ int sc_featnorm_apply(const float* feat, float* out, long long stride_b, long lo
 /* ---- Conv2d prenet (speechain/module/prenet/conv2d.py:168-205 construction, :227-280 forward) ---------------------------------
  * [Conv2d(kernel KH x KW, stride SH x SW, zero padding PH x PW) -> BatchNorm2d -> activation] blocks on a (B, T, F) feature image.
  * Every intermediate is channels-last: (B, To, Fo, C), i.e. a (B*To*Fo, C) matrix in `dtype` (0 = f32, 1 = bf16).  Geometry
- * arguments must satisfy To = (Ti + 2 PH - KH) / SH + 1 (same for Fo).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope).
+ * arguments must satisfy To = (Ti + 2 PH - KH) / SH + 1 (same for Fo).  act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 Tanh (the Conv1d
+ * postnet of the TTS recipes, postnet/conv1d.py:117-127, runs its blocks through the same kernels as (B, T, 1, C) images).
  *
  * First block (one input channel, KK = KH*KW <= 15 taps; replaces nn.Conv2d(1, C) + nn.BatchNorm2d + activation at conv2d.py:171-190):
  *   sc_conv1_moments  moments[KK*KK + KK] (float64) = sum over all output positions of patch patch^T, then of patch; x is the (B, Ti, Fi)
@@ -201,6 +202,17 @@ long long sc_wgrad_grouped_workspace(int n, const int* n_out, const int* n_in);
 int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, float* const* dW, float* const* db, const int* n_out,
                      const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, int tile, void* workspace,
                      long long ws_bytes, hipStream_t stream);
+
+/* ---- FastSpeech2 glue (speechain/module/decoder/nar_tts.py) ------------------------------------------------------------------
+ * Length regulation (nar_tts.py:439-472, a Python loop of repeat_interleave / pad / cat over the batch): out[b][t][:] = x[b][k][:] for the
+ * token k whose frames [sum(dur[b][:k]), sum(dur[b][:k+1])) contain t, zeros beyond the last frame; and its adjoint, dx[b][k][:] = sum of
+ * dy[b][t][:] over the frames of token k that exist (t < T), in frame order (deterministic).  dur (B, L) f32 holds the rounded,
+ * non-negative frame counts the reference computes (proc_duration, :206-230), truncated as its `.long()` does.  L <= 2048.
+ * sc_avg_by_duration: FastSpeech2Decoder.average_scalar_by_duration (:150-204): out[b][k] = mean of frame[b][t] over the existing frames
+ * of token k, 0 when it has none -- without the reference's (B, L, T) index cube. */
+int sc_length_regulate_fwd(int dtype, const void* x, const float* dur, void* out, int B, int L, int T, int D, hipStream_t stream);
+int sc_length_regulate_bwd(int dtype, const void* dy, const float* dur, void* dx, int B, int L, int T, int D, hipStream_t stream);
+int sc_avg_by_duration(const float* frame, const float* dur, float* out, int B, int L, int T, hipStream_t stream);
 
 /* nn.LayerNorm over the last dim D of an (R, D) matrix (encoder.py:97-98,291-292; decoder.py:90-92; pos_enc.py:94-95);
  * mean/rstd (R,) are saved for the backward pass (may be null).  Backward returns dx and the parameter gradients;

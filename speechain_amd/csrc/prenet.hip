@@ -21,7 +21,7 @@
 
 namespace {
 
-enum { PACT_NONE = 0, PACT_RELU = 1, PACT_LEAKY = 2 };
+enum { PACT_NONE = 0, PACT_RELU = 1, PACT_LEAKY = 2, PACT_TANH = 3 };
 
 struct Geo {
   int B, Ti, Fi;          // input image (per channel)
@@ -32,11 +32,13 @@ struct Geo {
 __device__ __forceinline__ float pact(float v, int act, float slope) {
   if (act == PACT_RELU) return v > 0.f ? v : 0.f;
   if (act == PACT_LEAKY) return v > 0.f ? v : v * slope;
+  if (act == PACT_TANH) return tanhf(v);
   return v;
 }
 __device__ __forceinline__ float pact_grad(float v, int act, float slope) {  // torch: derivative at 0 is 0 (ReLU) / slope (LeakyReLU)
   if (act == PACT_RELU) return v > 0.f ? 1.f : 0.f;
   if (act == PACT_LEAKY) return v > 0.f ? 1.f : slope;
+  if (act == PACT_TANH) { const float t = tanhf(v); return 1.f - t * t; }
   return 1.f;
 }
 
@@ -888,7 +890,7 @@ SC_API int sc_bn_act_fwd(int dtype, const void* z, long long M, int C, const flo
                          hipStream_t stream) {
   SC_CHECK_ARG(z && scale && shift && y, "sc_bn_act_fwd: null pointer");
   SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_act_fwd: dtype must be 0 (f32) or 1 (bf16)");
-  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 2, "sc_bn_act_fwd: bad sizes M=%lld C=%d act=%d", M, C, act);
+  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 3, "sc_bn_act_fwd: bad sizes M=%lld C=%d act=%d", M, C, act);
   SC_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0), "sc_bn_act_fwd: buffers must be 16-byte aligned");
   long long rpb;
   const unsigned grid = apply_grid(M, C, &rpb);
@@ -907,7 +909,7 @@ SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, 
                          long long ws_bytes, hipStream_t stream) {
   SC_CHECK_ARG(z && dy && scale && shift && dz && workspace, "sc_bn_act_bwd: null pointer");
   SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_act_bwd: dtype must be 0 (f32) or 1 (bf16)");
-  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 2, "sc_bn_act_bwd: bad sizes M=%lld C=%d act=%d", M, C, act);
+  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 3, "sc_bn_act_bwd: bad sizes M=%lld C=%d act=%d", M, C, act);
   SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_bn_act_bwd: mean and rstd come together");
   SC_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dz % 16 == 0), "sc_bn_act_bwd: buffers must be 16-byte aligned");
   SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C) + 3LL * C * (long long)sizeof(float), "sc_bn_act_bwd: workspace too small");

@@ -1200,7 +1200,7 @@ def ctc_nll(logits, in_len, tgt, tgt_len, blank: int = 0, zero_infinity: bool = 
 # ---------------------------------------------------------------------------------------------------------------------
 # Conv2d prenet blocks (csrc/prenet.hip): channels-last (B, T', F', C) images in the compute dtype
 # ---------------------------------------------------------------------------------------------------------------------
-PACT = {None: 0, "ReLU": 1, "LeakyReLU": 2}
+PACT = {None: 0, "ReLU": 1, "LeakyReLU": 2, "Tanh": 3}  # (Tanh: blocks after the first only -- the Conv1d postnet of the TTS recipes)
 
 
 def conv_out_size(n: int, k: int, s: int, p: int) -> int:
@@ -1440,3 +1440,47 @@ class _Embedding(torch.autograd.Function):
 def embedding(table: torch.Tensor, ids: torch.Tensor, padding_idx: Optional[int] = None) -> torch.Tensor:
     """nn.Embedding lookup whose table gradient is produced without atomics (and straight into its gradient-bucket slot)."""
     return _Embedding.apply(table, ids, padding_idx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FastSpeech2 glue (csrc/tts.hip): length regulation and per-token averages
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _LengthRegulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dur, out_len):
+        require_gpu(x, "length regulation")
+        B, L, D = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        dur = dur.detach().to(torch.float32).contiguous()
+        out = torch.empty(B, out_len, D, dtype=x.dtype, device=x.device)
+        lib.call("sc_length_regulate_fwd", dcode(x), _p(x), _p(dur), _p(out), B, L, out_len, D, stream())
+        ctx.save_for_backward(dur)
+        ctx.meta = (B, L, D, out_len)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (dur,) = ctx.saved_tensors
+        B, L, D, T = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty(B, L, D, dtype=dy.dtype, device=dy.device)
+        lib.call("sc_length_regulate_bwd", dcode(dy), _p(dy), _p(dur), _p(dx), B, L, T, D, stream())
+        return dx, None, None
+
+
+def length_regulate(x: torch.Tensor, duration: torch.Tensor, out_len: int) -> torch.Tensor:
+    """(B, L, D) token rows -> (B, out_len, D) frame rows: row k of utterance b repeated int(duration[b][k]) times, zero rows behind the
+    last frame, cut at out_len (speechain/module/decoder/nar_tts.py:439-472)."""
+    return _LengthRegulate.apply(x, duration, int(out_len))
+
+
+def avg_by_duration(frame_scalar: torch.Tensor, duration: torch.Tensor) -> torch.Tensor:
+    """(B, T) frame-level scalar -> (B, L) per-token means over each token's frames, 0 for a token without frames
+    (FastSpeech2Decoder.average_scalar_by_duration, decoder/nar_tts.py:150-204).  Targets only: not differentiated."""
+    require_gpu(frame_scalar, "average_scalar_by_duration")
+    f = frame_scalar.detach().to(torch.float32).contiguous()
+    d = duration.detach().to(torch.float32).contiguous()
+    out = torch.empty(d.shape, dtype=torch.float32, device=f.device)
+    lib.call("sc_avg_by_duration", _p(f), _p(d), _p(out), f.size(0), d.size(1), f.size(1), stream())
+    return out

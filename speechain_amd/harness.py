@@ -62,3 +62,44 @@ class ASRTransformer(torch.nn.Module):
         loss = (1 - self.ctc_weight) * ce + self.ctc_weight * ctc
         # (enc_hidden: the per-layer encoder outputs, encoder.py:339-343 -- a trainer that cuts backward into pieces uses them as cut points)
         return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=loss, enc_hidden=enc_hidden)
+
+
+class TTSFastSpeech2(torch.nn.Module):
+    """FastSpeech2 training step as SpeeChain's ``FastSpeech2`` model wires it (model/nar_tts.py:240-470 module_forward, :472-560
+    criterion_forward): TTSEncoder -> FastSpeech2Decoder -> feat L1 (before + after the postnet) + pitch / energy / log-duration L2.
+    `conf`: the ``module_conf`` of a recipe (e.g. recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:150-249) -- ``enc_emb``,
+    ``encoder``, the three predictors, ``feat_frontend``, the normalisation switches, ``decoder``, ``dec_postnet``."""
+
+    def __init__(self, vocab_size: int, conf: dict, reduction_factor: int = 1):
+        super().__init__()
+        from speechain_amd.criterion.least_error import LeastError
+        from speechain_amd.module.decoder.nar_tts import FastSpeech2Decoder
+        from speechain_amd.module.encoder.tts import TTSEncoder
+
+        self.encoder = TTSEncoder(vocab_size=vocab_size, embedding=conf["enc_emb"], encoder=conf["encoder"], prenet=conf.get("enc_prenet"))
+        self.decoder = FastSpeech2Decoder(
+            input_size=self.encoder.output_size, decoder=conf["decoder"], postnet=conf["dec_postnet"], pitch_predictor=conf["pitch_predictor"],
+            energy_predictor=conf["energy_predictor"], duration_predictor=conf["duration_predictor"], feat_frontend=conf.get("feat_frontend"),
+            feat_normalize=conf.get("feat_normalize", True), pitch_normalize=conf.get("pitch_normalize", True),
+            energy_normalize=conf.get("energy_normalize", True), reduction_factor=reduction_factor)
+        self.feat_loss = LeastError(loss_type="L1")
+        self.pitch_loss, self.energy_loss, self.duration_loss = (LeastError(loss_type="L2") for _ in range(3))
+
+    def forward(self, text, text_len, duration, duration_len, feat, feat_len, pitch, pitch_len, epoch: int = 1):
+        """text (B, L) WITHOUT <sos/eos> (module_forward strips them, model/nar_tts.py:366-368); duration (B, L) in any unit (rescaled to
+        the frame count); feat (B, T_w, 1) waveforms; pitch (B, T) frame-level."""
+        enc_text, enc_mask, _, _ = self.encoder(text=text, text_len=text_len)
+        (before, after, pred_len, tgt_feat, tgt_feat_len, pred_pitch, tgt_pitch, tgt_pitch_len, pred_energy, tgt_energy, tgt_energy_len,
+         pred_dur, pred_gate, used_dur, used_dur_len, _, _) = self.decoder(
+            enc_text=enc_text, enc_text_mask=enc_mask, duration=duration, duration_len=duration_len, pitch=pitch, pitch_len=pitch_len,
+            feat=feat, feat_len=feat_len, epoch=epoch, min_frame_num=0)
+        terms = dict(feat_before=self.feat_loss(pred=before, tgt=tgt_feat, tgt_len=tgt_feat_len),
+                     feat_after=self.feat_loss(pred=after, tgt=tgt_feat, tgt_len=tgt_feat_len),
+                     pitch=self.pitch_loss(pred=pred_pitch, tgt=tgt_pitch, tgt_len=tgt_pitch_len),
+                     energy=self.energy_loss(pred=pred_energy, tgt=tgt_energy, tgt_len=tgt_energy_len),
+                     duration=self.duration_loss(pred=pred_dur, tgt=torch.log(used_dur.float() + 1), tgt_len=used_dur_len))
+        out = dict(enc_text=enc_text, before=before, after=after, tgt_feat=tgt_feat, tgt_feat_len=tgt_feat_len, pred_pitch=pred_pitch,
+                   tgt_pitch=tgt_pitch, pred_energy=pred_energy, tgt_energy=tgt_energy, pred_dur=pred_dur, used_dur=used_dur,
+                   loss=sum(terms.values()))
+        out.update({"loss_" + k: v for k, v in terms.items()})
+        return out

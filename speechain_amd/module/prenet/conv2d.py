@@ -48,7 +48,7 @@ class Conv2dPrenet(Module):
             feat_dim = self.input_size
         elif feat_dim is None:
             raise RuntimeError
-        if conv_activation not in Fn.PACT:
+        if conv_activation not in (None, "ReLU", "LeakyReLU"):  # (the first block's fused kernels know these; Tanh exists for the Conv1d postnet only)
             raise NotImplementedError(f"speechain_amd Conv2dPrenet implements ReLU, LeakyReLU and no activation, got {conv_activation}")
         pair = lambda v: tuple(v) if isinstance(v, List) else (v, v)
         self.conv_dims = conv_dims if isinstance(conv_dims, List) else [conv_dims]

@@ -10,29 +10,12 @@ import torch.nn as nn
 
 from speechain_amd import functional as Fn
 from speechain_amd.module.abs import Module
+from speechain_amd.module.prenet.conv1d import Conv1dEv, shifted_cat
 
 
-class Conv1dSame(nn.Module):
-    """Odd-kernel stride-1 zero-padded Conv1d holder with the reference's parameter names (prenet/conv1d.py:73-90,
-    ``conv_lyr.weight`` (out, in, k)).  Evaluated as a GEMM over the k time-shifted copies of the input."""
-
-    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, **kw):
-        super().__init__()
-        if kernel_size % 2 == 0 or kw.get("stride", 1) != 1 or kw.get("dilation", 1) != 1 or kw.get("padding_mode", "same") != "same":
-            raise NotImplementedError("speechain_amd conv feed-forward implements odd-kernel, stride-1, 'same' convolutions")
-        self.conv_lyr = nn.Conv1d(in_channels, out_channels, kernel_size, padding=(kernel_size - 1) // 2, bias=kw.get("bias", True))
-        self.kernel_size = kernel_size
-
-    def gemm_weight(self) -> torch.Tensor:
-        w = self.conv_lyr.weight  # (out, in, k) -> (out, k*in) matching shifted_cat's column order
-        return w.permute(0, 2, 1).reshape(w.size(0), -1)
-
-
-def shifted_cat(x: torch.Tensor, k: int) -> torch.Tensor:
-    """(B, T, d) -> (B, T, k*d): [x[t-r], ..., x[t], ..., x[t+r]] with zero padding (the im2col of a 'same' Conv1d)."""
-    r = (k - 1) // 2
-    xp = torch.nn.functional.pad(x, (0, 0, r, r))
-    return torch.cat([xp[:, j: j + x.size(1)] for j in range(k)], dim=-1)
+def Conv1dSame(in_channels: int, out_channels: int, kernel_size: int = 3, **kw) -> Conv1dEv:
+    """The k-tap 'same' Conv1d of the conv feed-forward (feed_forward.py:62-75 builds Conv1dEv(..., **fdfwd_args))."""
+    return Conv1dEv(in_channels, out_channels, kernel_size, **kw)
 
 
 class PositionwiseFeedForward(Module):

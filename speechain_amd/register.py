@@ -29,6 +29,13 @@ OVERLAY = {
     "speechain.module.transformer.decoder": "speechain_amd.module.transformer.decoder",
     "speechain.module.prenet.conv2d": "speechain_amd.module.prenet.conv2d",
     "speechain.module.prenet.linear": "speechain_amd.module.prenet.linear",
+    "speechain.module.prenet.conv1d": "speechain_amd.module.prenet.conv1d",
+    "speechain.module.prenet.var_pred": "speechain_amd.module.prenet.var_pred",
+    "speechain.module.prenet.embed": "speechain_amd.module.prenet.embed",
+    "speechain.module.postnet.conv1d": "speechain_amd.module.postnet.conv1d",
+    "speechain.module.encoder.tts": "speechain_amd.module.encoder.tts",
+    "speechain.module.decoder.nar_tts": "speechain_amd.module.decoder.nar_tts",
+    "speechain.criterion.least_error": "speechain_amd.criterion.least_error",
     "speechain.module.postnet.token": "speechain_amd.module.postnet.token",
     "speechain.criterion.cross_entropy": "speechain_amd.criterion.cross_entropy",
     "speechain.criterion.ctc": "speechain_amd.criterion.ctc",

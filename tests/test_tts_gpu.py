@@ -1,0 +1,186 @@
+"""GPU: the FastSpeech2 path (BASELINE configs[4]) -- TTSEncoder + FastSpeech2Decoder (variance predictors, duration
+handling, average_scalar_by_duration, length regulation, decoder stack, Conv1d postnet with BatchNorm1d + Tanh) + the five LeastError
+terms -- against the fixture captured from the imported reference (tests/golden/g10_tts.npz) and against the CPU oracle."""
+import copy
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import cpu_ref as R
+from speechain_amd import functional as Fn
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+SMALL = dict(d=32, heads=2, layers=2, ffn=64, pred=16, post=16, vocab=20)
+
+
+def small_conf(c=SMALL, dropout=0.0):
+    """The module_conf of recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:150-249 at the fixture's sizes (the same
+    dictionaries tests/golden/make_golden.py::tts_confs hands to the reference)."""
+    trf = dict(posenc_dropout=dropout, posenc_scale=True, emb_scale=False, emb_layernorm=True, d_model=c["d"], num_heads=c["heads"],
+               num_layers=c["layers"], att_dropout=dropout, fdfwd_dim=c["ffn"], fdfwd_type="conv", fdfwd_args=dict(kernel_size=3),
+               fdfwd_dropout=dropout, res_dropout=dropout, layernorm_first=True, posenc_maxlen=400)
+    pred = lambda n, k, emb: dict(type="prenet.var_pred.Conv1dVarPredictor",
+                                  conf=dict(conv_dims=[c["pred"]] + [-1] * (n - 1), conv_kernel=k, conv_dropout=dropout,
+                                            **(dict(conv_emb_kernel=1, conv_emb_dropout=0.0) if emb else {})))
+    return dict(
+        enc_emb=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=c["d"])),
+        encoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)),
+        duration_predictor=pred(2, 3, False), pitch_predictor=pred(3, 5, True), energy_predictor=pred(2, 3, True),
+        feat_frontend=dict(type="frontend.speech2mel.Speech2MelSpec", conf=dict(sr=22050, mag_spec=True, hop_length=256, win_length=1024, n_mels=80,
+                                                                                fmin=0, fmax=8000, log_base=None, clamp=1e-5)),
+        feat_normalize=True, pitch_normalize=True, energy_normalize=True,
+        decoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)),
+        dec_postnet=dict(type="postnet.conv1d.Conv1dPostnet", conf=dict(conv_dims=[c["post"], -1, 0], conv_kernel=5, conv_batchnorm=True,
+                                                                         conv_activation="Tanh", conv_dropout=dropout)))
+
+
+SEL = {"g_emb": "encoder.embedding.embed.weight", "g_enc0_ffn_in": "encoder.encoder.trfm_layers.0.feed_forward.in_layer.conv_lyr.weight",
+       "g_dur_conv0": "decoder.duration_predictor.conv.0.conv_lyr.weight", "g_dur_ln0": "decoder.duration_predictor.conv.2.weight",
+       "g_dur_lin": "decoder.duration_predictor.linear.weight", "g_pitch_emb_w": "decoder.pitch_predictor.conv_emb.0.conv_lyr.weight",
+       "g_pitch_emb_b": "decoder.pitch_predictor.conv_emb.0.conv_lyr.bias", "g_energy_conv1": "decoder.energy_predictor.conv.4.conv_lyr.weight",
+       "g_dec1_q": "decoder.decoder.trfm_layers.1.multihead_att.q_layer.weight", "g_dec_alpha": "decoder.decoder.posenc.alpha",
+       "g_feat_pred": "decoder.feat_pred.weight", "g_post0": "decoder.postnet.conv.0.conv_lyr.weight",
+       "g_post_bn1_w": "decoder.postnet.conv.1.weight", "g_post_last": "decoder.postnet.conv.8.conv_lyr.weight",
+       "g_post_bn_last_b": "decoder.postnet.conv.9.bias"}
+
+
+@pytest.mark.parametrize("mode", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fastspeech2_two_steps_vs_reference_fixture(golden, mode):
+    """The reference's state dict loads into the drop-in modules key for key; two training steps (SGD move on fifteen parameters in
+    between, as the fixture's generator made) reproduce its outputs, loss terms, gradients and buffers.  f32 mode: 5e-4 abs on
+    activations, 1e-4 rel on losses, 2e-3 of each gradient's scale; bf16: rounding-level bounds."""
+    from speechain_amd.harness import TTSFastSpeech2
+
+    g = golden("g10_tts")
+    f32 = mode == torch.float32
+    Fn.set_compute_dtype(mode)
+    try:
+        torch.manual_seed(0)
+        model = TTSFastSpeech2(SMALL["vocab"], small_conf()).train()
+        sd = {k[len("sd0."):]: v for k, v in g.items() if k.startswith("sd0.")}
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
+        allowed = ("posenc.posenc", "mel_fbanks", "preemph")  # constants the fixture leaves out (rebuilt identically by the constructors)
+        assert all(any(a in k for a in allowed) for k in res.missing_keys), res.missing_keys
+        model = model.cuda()
+        params = dict(model.named_parameters())
+        dev = lambda t: t.cuda()
+        for step in range(2):
+            t = f"s{step}."
+            out = model(dev(g[t + "text"]), dev(g["text_len"]), dev(g[t + "dur"]), dev(g["text_len"]), dev(g[t + "wave"]), dev(g["wave_len"]),
+                        dev(g[t + "pitch"]), dev(g["pitch_len"]), epoch=1)
+            assert torch.equal(out["tgt_feat_len"].cpu(), g[t + "tgt_feat_len"])
+            assert torch.equal(out["used_dur"].cpu().float(), g[t + "used_dur"].float())
+            act = dict(atol=5e-4, rtol=1e-3) if f32 else dict(atol=0.12, rtol=5e-2)
+            for k in ("tgt_feat", "tgt_pitch", "tgt_energy"):  # targets: frontend + normalisation + per-token averages (float32 in both modes)
+                assert torch.allclose(out[k].float().cpu(), g[t + k], atol=2e-3, rtol=1e-3), (step, k, float((out[k].float().cpu() - g[t + k]).abs().max()))
+            for k in ("enc_text", "before", "after", "pred_pitch", "pred_energy", "pred_dur"):
+                assert torch.allclose(out[k].float().cpu(), g[t + k], **act), (step, k, float((out[k].float().cpu() - g[t + k]).abs().max()))
+            for k in ("feat_before", "feat_after", "pitch", "energy", "duration"):
+                a, b = float(out["loss_" + k]), float(g[t + "loss_" + k])
+                assert abs(a - b) < (2e-4 if f32 else 3e-2) * max(1.0, abs(b)), (step, k, a, b)
+            model.zero_grad(set_to_none=True)
+            out["loss"].backward()
+            for name, key in SEL.items():
+                gr, ref = params[key].grad.float().cpu(), g[t + name]
+                scale = float(ref.abs().max())
+                # (bf16: a sanity bound only -- small gradients at the end of long chains, and sums with cancellation such as the positional
+                # encoding scale, carry rounding errors of the size of the value itself; the f32 mode is the parity check)
+                tol = (2e-3 if f32 else 0.3) * scale + (1e-6 if f32 else 5e-4)
+                assert float((gr - ref).abs().max()) < tol, (step, name, float((gr - ref).abs().max()), scale)
+            if step == 0:
+                with torch.no_grad():
+                    for key in SEL.values():
+                        params[key] -= 0.05 * params[key].grad
+                Fn.weights.invalidate()
+        bufs = dict(model.named_buffers())
+        for k, ref in g.items():
+            if not k.startswith("buf1."):
+                continue
+            name = k[len("buf1."):]
+            assert name in bufs, name
+            got = bufs[name].float().cpu().reshape(-1)
+            if name.endswith("num_batches_tracked") or name.endswith("_batch"):
+                assert torch.equal(got, ref.float().reshape(-1)), name
+            else:
+                assert torch.allclose(got, ref.float().reshape(-1), atol=(2e-4 if f32 else 3e-2), rtol=(1e-3 if f32 else 5e-2)), \
+                    (name, float((got - ref.float().reshape(-1)).abs().max()))
+    finally:
+        Fn.set_compute_dtype(None)
+        Fn.weights.invalidate()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_length_regulation_and_its_adjoint(dtype):
+    """sc_length_regulate_fwd / _bwd against the reference's loop restated in the oracle: tokens without frames (also leading and
+    trailing), durations that overshoot the output length (cut) and undershoot it (zero rows), D not a multiple of 8."""
+    gen = torch.Generator().manual_seed(5)
+    for (B, L, D, T) in [(3, 9, 40, 37), (2, 130, 384, 640), (1, 5, 7, 12)]:
+        dur = torch.randint(0, 7, (B, L), generator=gen).float()
+        dur[0, 0] = 0
+        dur[-1, -2:] = 0
+        dur[0, 3] = 9
+        x = torch.randn(B, L, D, generator=gen).to(dtype)
+        w = torch.randn(B, T, D, generator=gen)
+        xr = x.float().clone().requires_grad_()
+        ref = R.length_regulate(xr, dur, torch.full((B,), T))
+        (ref * w).sum().backward()
+        xg = x.cuda().requires_grad_()
+        out = Fn.length_regulate(xg, dur.cuda(), T)
+        assert out.shape == (B, T, D) and torch.equal(out.float().cpu(), ref.detach())  # a copy: exact in either dtype
+        (out.float() * w.cuda()).sum().backward()
+        tol = dict(atol=1e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=0.05, rtol=2e-2)
+        # (bf16: the incoming gradient is rounded once, the per-token sum is accumulated in float32 and rounded once)
+        gin = (w.to(dtype).float() if dtype == torch.bfloat16 else w)
+        ref_g = torch.autograd.grad((R.length_regulate(xr, dur, torch.full((B,), T)) * gin).sum(), xr)[0]
+        assert torch.allclose(xg.grad.float().cpu(), ref_g, **tol), float((xg.grad.float().cpu() - ref_g).abs().max())
+
+
+def test_average_by_duration(golden):
+    g = golden("g10_tts")
+    out = Fn.avg_by_duration(g["avg_frame"].cuda(), g["avg_dur"].cuda())
+    assert torch.allclose(out.cpu(), g["avg_out"], atol=1e-6)
+    gen = torch.Generator().manual_seed(9)
+    frame = torch.randn(4, 200, generator=gen)
+    dur = torch.randint(0, 9, (4, 60), generator=gen).float()
+    assert torch.allclose(Fn.avg_by_duration(frame.cuda(), dur.cuda()).cpu(), R.average_scalar_by_duration(frame, dur), atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv1d_postnet_eval_and_train_vs_oracle(mode):
+    """Conv1dPostnet (5 blocks as in the recipe, kernel 5, BatchNorm1d + Tanh) on a padded batch: training mode (batch statistics over
+    all B*T positions, running statistics updated) and eval mode (running statistics) against F.conv1d / F.batch_norm / tanh."""
+    from speechain_amd.module.postnet.conv1d import Conv1dPostnet
+
+    torch.manual_seed(3)
+    post = Conv1dPostnet(input_size=80, conv_dims=[48, -1, -1, -1, 0], conv_kernel=5, conv_batchnorm=True, conv_activation="Tanh", conv_dropout=0.0)
+    for p in post.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+        else:
+            torch.nn.init.normal_(p, 1.0 if p.dim() == 1 and p.mean() > 0.5 else 0.0, 0.2)
+    x = torch.randn(3, 29, 80)
+    P = {"conv." + k: v.detach().clone() for k, v in post.conv.state_dict().items()}
+    f32 = mode == torch.float32
+    tol = dict(atol=3e-4, rtol=1e-3) if f32 else dict(atol=6e-2, rtol=5e-2)
+    Fn.set_compute_dtype(mode)
+    try:
+        g = post.cuda().train()
+        y = g(x.cuda(), torch.tensor([29, 20, 11]).cuda())
+        ref, stats = R.conv1d_postnet(x, P, "", 5, True)
+        assert torch.allclose(y.float().cpu(), ref, **tol), float((y.float().cpu() - ref).abs().max())
+        for k, v in stats.items():
+            assert torch.allclose(dict(g.named_buffers())[k].cpu(), v, atol=(1e-5 if f32 else 2e-2), rtol=(1e-4 if f32 else 5e-2)), k
+        P.update(stats)
+        y2 = g.eval()(x.cuda(), torch.tensor([29, 20, 11]).cuda())
+        if f32:  # (bf16 running statistics differ at rounding level from the oracle's, checked above)
+            ref2, _ = R.conv1d_postnet(x, P, "", 5, False)
+            assert torch.allclose(y2.float().cpu(), ref2, **tol), float((y2.float().cpu() - ref2).abs().max())
+    finally:
+        Fn.set_compute_dtype(None)
+        Fn.weights.invalidate()
