@@ -36,7 +36,9 @@ def parse():
     #  measured inside the timed region -- and takes ~26 ms instead of ~12.7; over 20 steps that alone adds 0.65 ms to the average)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend"])
+    ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend", "tts_train_step"],
+                    help="asr_train_step = the headline metric (BASELINE configs[2]); frontend = configs[1]; tts_train_step = configs[4] "
+                         "(FastSpeech2 train step, 32 x 7.4 s @ 22.05 kHz: a secondary line with its own metric name)")
     ap.add_argument("--prenet-dims", default="64,64",
                     help="conv channels of the Conv2d prenet in front of the encoder (SURVEY row f2; HIP path, FLOPs outside the named-path count). "
                          "64,64 = the transformer-wide recipes (and the module default); 512,512 = the transformer-large recipes (conv_dims = d_model)")
@@ -428,6 +430,139 @@ class ASRTrainStepWorkload:
                         "FETCH_SIZE x 2 + WRITE_SIZE over eager steps, averaged over the mix of shapes the kernel serves)"}
 
 
+# ---- BASELINE configs[4]: FastSpeech2 train step -----------------------------------------------------
+TTS_SAMPLES, TTS_FRAMES, TTS_TOKENS, TTS_VOCAB = 163584, 640, 128, 75
+
+
+def tts_recipe_conf(dropout_trf=0.2, dropout_conv=0.5):
+    """module_conf of recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:150-249 (d 384, 2 heads, 4 + 4 layers, conv feed-forward
+    1536 k3, predictors 256 channels, postnet 256 x 4 + back to 80, trmf_dropout 0.2, conv_dropout 0.5)."""
+    trf = dict(posenc_dropout=dropout_trf, posenc_scale=True, emb_scale=False, emb_layernorm=True, d_model=384, num_heads=2, num_layers=4,
+               att_dropout=dropout_trf, fdfwd_dim=1536, fdfwd_type="conv", fdfwd_args=dict(kernel_size=3), fdfwd_dropout=dropout_trf,
+               res_dropout=dropout_trf, layernorm_first=True)
+    vp = "prenet.var_pred.Conv1dVarPredictor"
+    return dict(
+        enc_emb=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=384)),
+        encoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)),
+        duration_predictor=dict(type=vp, conf=dict(conv_dims=[256, -1], conv_kernel=3, conv_dropout=dropout_conv)),
+        pitch_predictor=dict(type=vp, conf=dict(conv_dims=[256, -1, -1, -1, -1], conv_kernel=5, conv_dropout=dropout_conv, conv_emb_kernel=1,
+                                                conv_emb_dropout=0.0)),
+        energy_predictor=dict(type=vp, conf=dict(conv_dims=[256, -1], conv_kernel=3, conv_dropout=dropout_conv, conv_emb_kernel=1,
+                                                 conv_emb_dropout=0.0)),
+        feat_frontend=dict(type="frontend.speech2mel.Speech2MelSpec", conf=dict(sr=22050, mag_spec=True, hop_length=256, win_length=1024, n_mels=80,
+                                                                                fmin=0, fmax=8000, log_base=None, clamp=1e-5)),
+        feat_normalize=True, pitch_normalize=True, energy_normalize=True,
+        decoder=dict(type="transformer.encoder.TransformerEncoder", conf=dict(trf)),
+        dec_postnet=dict(type="postnet.conv1d.Conv1dPostnet", conf=dict(conv_dims=[256, -1, -1, -1, 0], conv_kernel=5, conv_batchnorm=True,
+                                                                         conv_activation="Tanh", conv_dropout=dropout_conv)))
+
+
+def synth_tts(seed: int, device, nb: int = BATCH):
+    """phoneme ids uniform in [1, 75), 128 tokens after the <sos/eos> strip, 163 584 samples at 22 050 Hz (640 frames at
+    hop 256), 5 frames per token, frame-level pitch ~ N(0, 1)."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    text = torch.randint(1, TTS_VOCAB, (nb, TTS_TOKENS), generator=g)
+    text_len = torch.full((nb,), TTS_TOKENS, dtype=torch.int64)
+    dur = torch.full((nb, TTS_TOKENS), 5.0)
+    wave = torch.randn(nb, TTS_SAMPLES, 1, generator=g) * 0.1
+    wave_len = torch.full((nb,), TTS_SAMPLES, dtype=torch.int64)
+    pitch = torch.randn(nb, TTS_FRAMES, generator=g)
+    pitch_len = torch.full((nb,), TTS_FRAMES, dtype=torch.int64)
+    return [t.to(device) for t in (text, text_len, dur, text_len.clone(), wave, wave_len, pitch, pitch_len)]
+
+
+class TTSTrainStepWorkload:
+    """FastSpeech2 train step from waveforms: frontend (mel + energy) -> three global normalisations -> encoder -> variance predictors ->
+    length regulation -> decoder -> feat_pred + Conv1d postnet -> five-term loss -> backward -> clip 1.0 + Adam (Noam, warm-up 6000).
+    Eager launches (no hipGraph yet: the normalisations' running statistics and the duration arithmetic are host-sequenced), weight
+    gradients through the grouped launch, clip + Adam in two launches over the flat buckets."""
+
+    dtype = "bf16"
+    name = ("FastSpeech2 train step (4enc/4dec d384 h2 conv-ffn1536 k3, predictors 256, postnet 256x4, bf16) from 32x7.4s@22.05kHz "
+            "waveforms: frontend(mel+energy) + global normalisations + encoder + duration/pitch/energy predictors + length regulation + "
+            "decoder + postnet + L1/L2 losses + backward + clip + Adam (BASELINE configs[4])")
+
+    def __init__(self, device, seed, world, distributed=False):
+        from speechain_amd import functional as Fn
+        from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
+        from speechain_amd.harness import TTSFastSpeech2
+        from speechain_amd.optim import FusedAdam
+
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.set_attention_probs(False)
+        torch.manual_seed(0)
+        self.model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf()).to(device).train()
+        for p in self.model.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, adjacent=attention_fusion_groups(self.model))
+        self.reducer.broadcast_parameters()
+        self.lr = torch.tensor([1e-3], device=device)
+        self.opt = FusedAdam(self.reducer, self.lr, betas=(0.9, 0.98), eps=1e-9, max_grad_norm=1.0)
+        torch.manual_seed(1234 + seed)
+        self.batch = synth_tts(seed, device)
+        self.nstep, self.world = 0, world
+        self.ev, self.flops, self.launch_flops, self.launch_kernels = [], 0.0, [], []
+
+    def step(self, timed: bool, instrument: bool = False):
+        from speechain_amd import functional as Fn
+        from speechain_amd._lib import lib
+
+        self.nstep += 1
+        self.lr.fill_(384 ** -0.5 * min(self.nstep ** -0.5, self.nstep * 6000 ** -1.5))
+        if instrument:
+            lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev, "sc_wgrad_grouped": self.ev}
+            lib.flop_log, lib.kernel_log = [], []
+        Fn.DropoutState.advance()
+        Fn.weights.refresh()
+        self.reducer.zero_grad()
+        out = self.model(*self.batch, epoch=1)
+        out["loss"].backward()
+        self.reducer.wait()
+        self.opt.step()
+        if instrument:
+            self.flops += sum(lib.flop_log)
+            self.launch_flops += lib.flop_log
+            self.launch_kernels += lib.kernel_log
+            lib.timing = lib.flop_log = lib.kernel_log = None
+        return out["loss"].detach()
+
+    roofline = None  # bound below: the GEMM roofline code of the ASR workload works on the same logs
+
+
+def cpu_baseline_tts(seconds: float):
+    """The oracle's FastSpeech2 step (forward + backward, no optimizer) on the host cores over 4 of the 32 utterances."""
+    from oracle import cpu_ref as R
+    from speechain_amd.harness import TTSFastSpeech2
+
+    cores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", 16)))
+    torch.set_num_threads(cores)
+    nb = 4
+    torch.manual_seed(0)
+    model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf())
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and not k.endswith("posenc") and
+                                              "mel_fbanks" not in k and "preemph" not in k) for k, v in model.state_dict().items()}
+    cfg = dict(d=384, heads=2, layers=4, dur_layers=2, pitch_layers=5, energy_layers=2, post_layers=5)
+    text, text_len, dur, _, wave, wave_len, pitch, pitch_len = synth_tts(0, "cpu", nb)
+    norms = {k: R.FeatureNormalization() for k in ("feat", "pitch", "energy")}
+
+    def one():
+        out = R.fastspeech2_forward_loss(text, text_len, dur, wave, wave_len, pitch, pitch_len, P, cfg, norms, epoch=1)
+        out["loss"].backward()
+
+    one()
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > seconds or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(nb * n / dt, 4), unit="utterances/s", cores=cores, kind="port",
+                sample=f"{n} FastSpeech2 steps (fwd+bwd, no optimizer) over {nb} of the 32 utterances each, torch-CPU oracle, fp32, {cores} threads, {dt:.1f} s")
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
     for name in ("r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
@@ -545,7 +680,13 @@ def main():
 
     torch.manual_seed(1234 + rank)
     prenet_dims = tuple(int(c) for c in args.prenet_dims.split(","))
-    wl = FrontendWorkload(device, seed=rank) if args.workload == "frontend" else ASRTrainStepWorkload(device, rank, world, prenet_dims, distributed=dist is not None)
+    if args.workload == "frontend":
+        wl = FrontendWorkload(device, seed=rank)
+    elif args.workload == "tts_train_step":
+        TTSTrainStepWorkload.roofline = ASRTrainStepWorkload.roofline
+        wl = TTSTrainStepWorkload(device, rank, world, distributed=dist is not None)
+    else:
+        wl = ASRTrainStepWorkload(device, rank, world, prenet_dims, distributed=dist is not None)
     for _ in range(args.warmup):
         wl.step(False)
 
@@ -561,7 +702,7 @@ def main():
         wl.step(True)  # every timed step is the same replayed step
     fence()
     elapsed = time.perf_counter() - t0
-    if args.workload == "asr_train_step":
+    if args.workload in ("asr_train_step", "tts_train_step"):
         # one more step, eager, with HIP events around every GEMM launch: the roofline's per-kernel times.  It runs right AFTER the timed
         # region (it takes about twice a replayed step and, on several ranks, uses the hook-launched all-reduce path), in the same
         # process, on the same weights and inputs; every rank runs it (its collectives need all of them), rank 0 reports its events.
@@ -584,7 +725,8 @@ def main():
         else:
             roof = wl.roofline()
         line = {
-            "metric": "utterances/sec (10 s@16 kHz, bsz32)",
+            "metric": ("utterances/sec (7.4 s@22.05 kHz, bsz32) FastSpeech2 train step" if args.workload == "tts_train_step" else
+                       "utterances/sec (10 s@16 kHz, bsz32)"),
             "value": round(BATCH * args.steps * world / elapsed, 2),
             "unit": "utterances/s",
             "n_gpus": world,
@@ -596,8 +738,10 @@ def main():
             "vs_baseline": None,
             "dtype": wl.dtype,
             "data": "synthetic",
-            "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": SAMPLES,
+            "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": TTS_SAMPLES if args.workload == "tts_train_step" else SAMPLES,
                        "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
+                                    f"dp{world}: per-GPU batch 32; eager launches; the gradient all-reduce in 32 MB flat buckets is issued from "
+                                    "the per-parameter hooks on a communication stream (a single rank: none)" if args.workload == "tts_train_step" else
                                     f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
                                     "buckets" + (" -- backward is replayed as five hipGraphs (cut at the encoder output, two encoder "
                                     "hidden states and the encoder input) and the buckets each piece completes are reduced on a "
@@ -617,7 +761,9 @@ def main():
                                        "note": "SURVEY.md section 8d config 3: 848 GFLOP forward x 3 of the named path (encoder, decoder, "
                                                "heads; prenet excluded) per 32-utterance step / measured step time / dense bf16 peak"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else cpu_baseline_train(args.cpu_seconds, prenet_dims)
+            line["cpu_baseline"] = (cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else
+                                    cpu_baseline_tts(args.cpu_seconds) if args.workload == "tts_train_step" else
+                                    cpu_baseline_train(args.cpu_seconds, prenet_dims))
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -1443,6 +1443,38 @@ def embedding(table: torch.Tensor, ids: torch.Tensor, padding_idx: Optional[int]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# im2col of a 'same' Conv1d: (B, T, C) -> (B, T, k*C) = [x[t-r], ..., x[t], ..., x[t+r]]  (zero rows outside the sequence)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _ShiftedCat(torch.autograd.Function):
+    """One launch of the prenet's im2col kernel on the (B, T, 1, C) image with a (k, 1) kernel -- and its gather-form adjoint -- instead of
+    pad + k slices + cat (three torch launches forward, 2k + 2 backward, per convolution)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        require_gpu(x, "conv1d im2col")
+        x = x if x.is_contiguous() else x.contiguous()
+        B, T, C = x.shape
+        g = (B, T, 1, C, T, 1, k, 1, 1, 1, (k - 1) // 2, 0)
+        col = torch.empty(B, T, k * C, dtype=x.dtype, device=x.device)
+        lib.call("sc_im2col", dcode(x), _p(x), *g, _p(col), stream())
+        ctx.g = g
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        g = ctx.g
+        dcol = dcol if dcol.is_contiguous() else dcol.contiguous()
+        dx = torch.empty(g[0], g[1], g[3], dtype=dcol.dtype, device=dcol.device)
+        lib.call("sc_col2im", dcode(dcol), _p(dcol), *g, _p(dx), stream())
+        return dx, None
+
+
+def shifted_cat(x: torch.Tensor, k: int) -> torch.Tensor:
+    return x if k == 1 else _ShiftedCat.apply(x, int(k))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # FastSpeech2 glue (csrc/tts.hip): length regulation and per-token averages
 # ---------------------------------------------------------------------------------------------------------------------
 

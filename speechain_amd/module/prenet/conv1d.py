@@ -9,12 +9,8 @@ from speechain_amd import functional as Fn
 
 
 def shifted_cat(x: torch.Tensor, k: int) -> torch.Tensor:
-    """(B, T, d) -> (B, T, k*d): [x[t-r], ..., x[t], ..., x[t+r]] with zero padding (the im2col of a 'same' Conv1d)."""
-    if k == 1:
-        return x
-    r = (k - 1) // 2
-    xp = torch.nn.functional.pad(x, (0, 0, r, r))
-    return torch.cat([xp[:, j: j + x.size(1)] for j in range(k)], dim=-1)
+    """(B, T, d) -> (B, T, k*d): [x[t-r], ..., x[t], ..., x[t+r]] with zero padding (the im2col of a 'same' Conv1d); one HIP launch."""
+    return Fn.shifted_cat(x, k)
 
 
 class Conv1dEv(nn.Module):
