@@ -195,13 +195,15 @@ int sc_gemm_splitk(int ta, int tb, const void* A, const void* B, float* C, int M
  * 16-byte aligned pointers).  tile: 0 = choose, 128 / 256 = force the output tile edge.  `workspace` (device memory,
  * sc_wgrad_grouped_workspace(n, n_out, n_in) bytes, 16-byte aligned) receives the schedule: the problems cut into units of at most 16
  * tiles, dealt to the 8 XCDs by work; it is filled by small launches that carry the entries as kernel arguments, so the call makes
- * no host-to-device copy and can be captured into a hipGraph. */
+ * no host-to-device copy and can be captured into a hipGraph.  conv_k (nullable; entries 0 / 1 = plain): problem g is the im2col product
+ * of a 'same' Conv1d with conv_k[g] taps (x[g] columns = tap * C_in + channel) and dW[g] is the nn.Conv1d weight gradient in ITS layout,
+ * (n_out, n_in / conv_k, conv_k): the epilogue stores element (o, tap * C + c) at (o, c, tap). */
 int sc_wgrad_grouped_supported(int n_out, int n_in, int tokens, long long ldz, long long ldx);
 int sc_wgrad_grouped_last_tile(void); /* measurement aid: tile edge the calling thread's last sc_wgrad_grouped call used */
 long long sc_wgrad_grouped_workspace(int n, const int* n_out, const int* n_in);
 int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, float* const* dW, float* const* db, const int* n_out,
-                     const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, int tile, void* workspace,
-                     long long ws_bytes, hipStream_t stream);
+                     const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, const int* conv_k, int tile,
+                     void* workspace, long long ws_bytes, hipStream_t stream);
 
 /* ---- FastSpeech2 glue (speechain/module/decoder/nar_tts.py) ------------------------------------------------------------------
  * Length regulation (nar_tts.py:439-472, a Python loop of repeat_interleave / pad / cat over the batch): out[b][t][:] = x[b][k][:] for the
@@ -308,10 +310,12 @@ int sc_embedding_bwd(int dtype, const long long* ids, const void* dy, long long 
 int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, long long ld_out, hipStream_t stream);
 
 /* Batched refresh of compute-dtype weight copies in ONE launch.  `desc` is a device array of n_desc records
- *   struct sc_cast_desc { const float* src; void* dst; void* dst_t; int rows, cols; long long ld_dst, ld_dst_t; int tile0, tiles_x; };
- * (56 bytes): record i owns tiles [tile0_i, tile0_{i+1}) of 32 x 32 elements of its (rows, cols) float32 matrix,
+ *   struct sc_cast_desc { const float* src; void* dst; void* dst_t; int rows, cols; long long ld_dst, ld_dst_t; int tile0, tiles_x;
+ *                         int conv_k, pad; };
+ * (64 bytes): record i owns tiles [tile0_i, tile0_{i+1}) of 32 x 32 elements of its (rows, cols) float32 matrix,
  * tiles_x = ceil(cols/32); each tile is written as `dtype_out` to dst (row stride ld_dst) and/or transposed to dst_t
- * (row stride ld_dst_t); null pointers are skipped.  total_tiles = sum of all records' tiles. */
+ * (row stride ld_dst_t); null pointers are skipped.  total_tiles = sum of all records' tiles.  conv_k > 1: src is an nn.Conv1d weight
+ * (rows, cols / conv_k, conv_k) (prenet/conv1d.py:99-108) read as the GEMM matrix of the 'same' convolution, column = tap * C_in + channel. */
 int sc_cast_weights(int dtype_out, const void* desc, int n_desc, int total_tiles, hipStream_t stream);
 
 /* y = dropout(x * xscale + table[t] * (*alpha)) for x (B, T, D), table (>= T, D) f32 (pos_enc.py:168-182). */

@@ -55,7 +55,7 @@ def run(which, tile, reps=10):
     args = (n, arr(ctypes.c_void_p, [t.data_ptr() for t in dz]), arr(ctypes.c_void_p, [t.data_ptr() for t in x]),
             arr(ctypes.c_void_p, [t.data_ptr() for t in dW]), arr(ctypes.c_void_p, [t.data_ptr() for t in db]),
             n_out, n_in, arr(ctypes.c_int, [p[2] for p in ps]),
-            arr(ctypes.c_longlong, [p[0] for p in ps]), arr(ctypes.c_longlong, [p[1] for p in ps]), tile, ws.data_ptr(), ws.numel())
+            arr(ctypes.c_longlong, [p[0] for p in ps]), arr(ctypes.c_longlong, [p[1] for p in ps]), None, tile, ws.data_ptr(), ws.numel())
     fn = lambda: lib.call("sc_wgrad_grouped", *args, stream())
     for _ in range(2):
         fn()

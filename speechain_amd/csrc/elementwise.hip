@@ -99,6 +99,7 @@ struct CastDesc {
   int rows, cols;
   long long ld_dst, ld_dst_t;
   int tile0, tiles_x;
+  int conv_k, pad_;  // conv_k > 1: src is a Conv1d weight (rows, cols / conv_k, conv_k); column c of the GEMM matrix = tap c / C, channel c % C
 };
 
 template <typename TO>
@@ -116,7 +117,12 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const CastDesc* desc,
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int j = ty; j < 32; j += 8) {
     const int r = r0 + j, c = c0 + tx;
-    const float v = (r < d.rows && c < d.cols) ? d.src[(long long)r * d.cols + c] : 0.f;
+    int cs = c;
+    if (d.conv_k > 1 && c < d.cols) {
+      const int C = d.cols / d.conv_k;
+      cs = (c % C) * d.conv_k + c / C;
+    }
+    const float v = (r < d.rows && c < d.cols) ? d.src[(long long)r * d.cols + cs] : 0.f;
     tile[j][tx] = v;
     if (d.dst && r < d.rows && c < d.cols) Io<TO>::st(d.dst, (long long)r * d.ld_dst + c, v);
   }

@@ -48,6 +48,7 @@ struct Prob {
   float* db;                 // (n_out) f32 column sums of dz, or null
   int n_out, n_in, tokens, tiles_n;
   int ldz, ldx;
+  int conv_k, pad_;          // conv_k > 1: dW is an nn.Conv1d weight (n_out, n_in / conv_k, conv_k); GEMM column = tap * C + channel
 };
 // The schedule lives in a device table (caller-provided workspace): header, per-unit tile offsets, per-unit descriptors.
 // Units are dealt to the 8 XCDs (each with its own L2) so that every XCD gets about the same amount of work AND all tiles of a unit
@@ -60,7 +61,7 @@ struct Header {
   int n_units;
   int pad[6];
 };
-constexpr int CHUNK = 56;  // table entries per writer launch
+constexpr int CHUNK = 48;  // table entries per writer launch
 struct Chunk {
   Prob p[CHUNK];
   int tile0[CHUNK];
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
       if (m < P.n_out && n < P.n_in) {
         const f32x4 v = *(const f32x4*)(stage + row * STG_LD + c4);
         float* dst = P.dW + (long long)m * P.n_in + n;
-        if (n + 4 <= P.n_in && vec) *(f32x4*)dst = v;
+        if (P.conv_k > 1) {  // Conv1d weight layout: GEMM column tap * C + c -> (c, tap)
+          const int C = P.n_in / P.conv_k;
+          for (int e = 0; e < 4 && n + e < P.n_in; ++e) P.dW[(long long)m * P.n_in + ((n + e) % C) * P.conv_k + (n + e) / C] = v[e];
+        } else if (n + 4 <= P.n_in && vec) *(f32x4*)dst = v;
         else for (int e = 0; e < 4 && n + e < P.n_in; ++e) dst[e] = v[e];
       }
     }
@@ -424,8 +428,8 @@ SC_API long long sc_wgrad_grouped_workspace(int n, const int* n_out, const int* 
 // workspace: device memory, sc_wgrad_grouped_workspace(n, n_out, n_in) bytes, 16-byte aligned; it must stay untouched until the
 // launches of this call have run.
 SC_API int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, float* const* dW, float* const* db, const int* n_out,
-                            const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, int tile, void* workspace,
-                            long long ws_bytes, hipStream_t stream) {
+                            const int* n_in, const int* tokens, const long long* ldz, const long long* ldx, const int* conv_k, int tile,
+                            void* workspace, long long ws_bytes, hipStream_t stream) {
   SC_CHECK_ARG(n >= 1 && dz && x && dW && db && n_out && n_in && tokens && ldz && ldx, "sc_wgrad_grouped: null array or empty list");
   SC_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "sc_wgrad_grouped: tile must be 0, 128 or 256");
   SC_CHECK_ARG(workspace && (uintptr_t)workspace % 16 == 0, "sc_wgrad_grouped: workspace is null or not 16-byte aligned");
@@ -435,6 +439,8 @@ SC_API int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, 
     SC_CHECK_ARG(sc_wgrad_grouped_supported(n_out[g], n_in[g], tokens[g], ldz[g], ldx[g]),
                  "sc_wgrad_grouped: problem %d (n_out=%d n_in=%d tokens=%d ldz=%lld ldx=%lld) is not supported", g, n_out[g], n_in[g],
                  tokens[g], ldz[g], ldx[g]);
+    SC_CHECK_ARG(!conv_k || conv_k[g] <= 1 || n_in[g] % conv_k[g] == 0, "sc_wgrad_grouped: problem %d: n_in %d is not a multiple of conv_k %d", g,
+                 n_in[g], conv_k ? conv_k[g] : 0);
     SC_CHECK_ARG((uintptr_t)dz[g] % 16 == 0 && (uintptr_t)x[g] % 16 == 0 && (uintptr_t)dW[g] % 16 == 0,
                  "sc_wgrad_grouped: problem %d has a pointer that is not 16-byte aligned", g);
     t256 += (long long)sc_cdiv(n_out[g], 256) * sc_cdiv(n_in[g], 256);
@@ -487,6 +493,7 @@ SC_API int sc_wgrad_grouped(int n, const void* const* dz, const void* const* x, 
       P.db = db[g] ? db[g] + u.m_base : nullptr;
       P.n_out = u.rows; P.n_in = n_in[g]; P.tokens = tokens[g];
       P.ldz = debug_ld0 ? 0 : (int)ldz[g]; P.ldx = debug_ld0 ? 0 : (int)ldx[g];
+      P.conv_k = (conv_k && conv_k[g] > 1) ? conv_k[g] : 1;
       P.tiles_n = sc_cdiv(n_in[g], tile);
       tile0[k++] = t0;
       t0 += u.tiles;

@@ -160,21 +160,31 @@ class _WeightCache:
             self.store = {k: v for k, v in self.store.items() if all(r() is not None for r in v[2])}
         self.store[key] = (self._ver(params), buf, tuple(weakref.ref(p) for p in params))
 
+    @staticmethod
+    def _matrix(p: torch.Tensor) -> torch.Tensor:
+        """The float32 (rows, K) GEMM matrix of a parameter: itself, or -- for an nn.Conv1d weight (out, in, k) of a 'same' convolution
+        evaluated over the k shifted copies of its input (shifted_cat) -- the (out, k * in) matrix whose column is tap * C_in + channel."""
+        p = p.detach()
+        if p.dim() == 3:
+            return p.permute(0, 2, 1).reshape(p.size(0), -1)
+        return p.contiguous()
+
     def fused(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
-        """Rows of all `params` (each (n_i, K) float32) stacked into one (sum n_i, K) matrix of `dtype`."""
-        if len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous():
+        """Rows of all `params` (each (n_i, K) float32, or a Conv1d weight (n_i, C, k) read as (n_i, k * C)) stacked into one
+        (sum n_i, K) matrix of `dtype`."""
+        if len(params) == 1 and params[0].dtype == dtype and params[0].is_contiguous() and params[0].dim() == 2:
             return params[0].detach()
         cacheable = all(p.is_leaf for p in params)  # derived tensors (e.g. reshaped conv weights) are cast on the fly
         key = (tuple(id(p) for p in params), dtype)
         hit = self._lookup(key, params) if cacheable else None
         if hit is not None and hit[0] == self._ver(params):
             return hit[1]
-        K = params[0].size(1)
+        K = params[0].numel() // params[0].size(0)
         rows = sum(p.size(0) for p in params)
         buf = hit[1] if hit is not None else torch.empty(rows, K, dtype=dtype, device=params[0].device)
         r = 0
         for p in params:
-            src = p.detach().contiguous()
+            src = self._matrix(p).contiguous()
             lib.call("sc_cast", F32, BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r * K), src.numel(), stream())
             r += p.size(0)
         if cacheable:
@@ -189,12 +199,12 @@ class _WeightCache:
         hit = self._lookup(key, params) if cacheable else None
         if hit is not None and hit[0] == self._ver(params):
             return hit[1]
-        K = params[0].size(1)
+        K = params[0].numel() // params[0].size(0)
         rows = sum(p.size(0) for p in params)
         buf = hit[1] if hit is not None else torch.empty(K, rows, dtype=dtype, device=params[0].device)
         r = 0
         for p in params:
-            src = p.detach().float().contiguous()
+            src = self._matrix(p).float().contiguous()
             lib.call("sc_cast_transpose", BF16 if dtype == torch.bfloat16 else F32, _p(src), _p(buf, r), p.size(0), K, rows, stream())
             r += p.size(0)
         if cacheable:
@@ -249,13 +259,14 @@ class _WeightCache:
                             rec = (p.data_ptr(), buf.data_ptr() + esz * r, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
                             r += cols
                         else:
-                            rows, cols = p.shape
+                            rows, cols = p.size(0), p.numel() // p.size(0)
                             if transposed:
                                 rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, buf.size(1), tile0, (cols + 31) // 32)
                             else:
                                 rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
                             r += rows
-                        recs.append(struct.pack("<QQQiiqqii", *rec))
+                        conv_k = p.size(2) if (p.dim() == 3 and k[1] != "vec") else 1
+                        recs.append(struct.pack("<QQQiiqqiiii", *rec, conv_k, 0))
                         tile0 += ((cols + 31) // 32) * ((rows + 31) // 32)
                 dev = ents[0][1][1].device
                 cur = (sig, torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev), len(recs), tile0)
@@ -387,15 +398,15 @@ class _WgradQueue:
     backward has ended, so the result is the same.  Entries hold raw addresses of the outputs (a lingering reference to the slot
     views would make autograd's accumulation clone them before they are written) and keep the operands alive."""
 
-    pending = []   # (dz address, x address, dW address, db address or 0, n_out, n_in, tokens, ldz, ldx)
+    pending = []   # (dz address, x address, dW address, db address or 0, n_out, n_in, tokens, ldz, ldx, conv_k)
     keep = []      # operand tensors
     armed = False
     enabled = _os.environ.get("SC_WGRAD_GROUPED", "1") == "1"  # (A/B knob)
 
     @classmethod
-    def add(cls, dz: torch.Tensor, x2: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor]):
+    def add(cls, dz: torch.Tensor, x2: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], conv_k: int = 1):
         cls.pending.append((dz.data_ptr(), x2.data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else 0, dz.size(1), x2.size(1),
-                            dz.size(0), dz.stride(0), x2.stride(0)))
+                            dz.size(0), dz.stride(0), x2.stride(0), conv_k))
         cls.keep.append((dz, x2))
         if not cls.armed:
             cls.armed = True
@@ -422,8 +433,8 @@ class _WgradQueue:
         n_out, n_in = col(4, ctypes.c_int), col(5, ctypes.c_int)
         ws = torch.empty(lib.value("sc_wgrad_grouped_workspace", n, n_out, n_in), dtype=torch.uint8, device=cls.keep[0][0].device)
         lib.call("sc_wgrad_grouped", n, col(0, ctypes.c_void_p), col(1, ctypes.c_void_p), col(2, ctypes.c_void_p), col(3, ctypes.c_void_p),
-                 n_out, n_in, col(6, ctypes.c_int), col(7, ctypes.c_longlong), col(8, ctypes.c_longlong), 0, ws.data_ptr(), ws.numel(),
-                 stream())
+                 n_out, n_in, col(6, ctypes.c_int), col(7, ctypes.c_longlong), col(8, ctypes.c_longlong), col(9, ctypes.c_int), 0, ws.data_ptr(),
+                 ws.numel(), stream())
         cls.pending.clear()
         cls.keep.clear()
 
@@ -436,6 +447,8 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
     too: the split-K kernel takes it from the dz tiles it streams anyway, otherwise a separate column-sum launch does."""
     M, N = dz.shape
     K = x2.size(1)
+    # a Conv1d weight (N, C, k) behind a product over the k shifted copies of the input: the gradient is wanted in the weight's own layout
+    conv_k = params[0].size(2) if (len(params) == 1 and params[0].dim() == 3) else 1
     sink = GradSinks.take(params) if params else None
     if (code == BF16 and sink is not None and _WgradQueue.enabled and dz.stride(1) == 1 and x2.stride(1) == 1
             and lib.value("sc_wgrad_grouped_supported", N, K, M, dz.stride(0), x2.stride(0))
@@ -444,11 +457,17 @@ def wgrad(code: int, dz: torch.Tensor, x2: torch.Tensor, params: Sequence[torch.
         if not bias or bsink is not None:
             # both outputs are bucket slots: the product joins the grouped launch at the end of this backward call
             dW = sink.view(N, K)
-            _WgradQueue.add(dz, x2, dW, bsink)
+            _WgradQueue.add(dz, x2, dW, bsink, conv_k)
             return (dW, bsink) if bias else dW
         dW = sink.view(N, K)  # (a bias outside the buckets: its column sums are taken now)
-        _WgradQueue.add(dz, x2, dW, None)
+        _WgradQueue.add(dz, x2, dW, None, conv_k)
         return dW, _colsum(dz, ())
+    if conv_k > 1:  # immediate path: the product in GEMM layout, then one permuting copy into the weight's layout
+        g2 = wgrad(code, dz, x2, (), bias=bias, bias_params=bias_params)
+        g2d, db = g2 if bias else (g2, None)
+        dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
+        dW.view(N, K // conv_k, conv_k).copy_(g2d.view(N, conv_k, K // conv_k).permute(0, 2, 1))
+        return (dW, db) if bias else dW
     dW = sink.view(N, K) if sink is not None else torch.empty(N, K, dtype=torch.float32, device=dz.device)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     # (at most 16 slices for the transformer's products, M ~ 8000; up to 64 for the prenet's conv weight gradient, whose contraction
@@ -620,7 +639,7 @@ class _Linear(torch.autograd.Function):
             # dW = dz^T x, and db = column sums of dz out of the same launch
             dW, db = wgrad(code, dz, x2, ws, bias=True, bias_params=ctx.bias_params if all(has_b) else ()) if any(has_b) \
                 else (wgrad(code, dz, x2, ws), None)
-            dws = list(dW.split(rows, dim=0))
+            dws = [g.view_as(w) for g, w in zip(dW.split(rows, dim=0), ws)]  # (a Conv1d weight gets its (out, in, k) shape back)
             dbs = [None] * len(rows)
             if any(has_b):
                 dbs = [g if hb else None for g, hb in zip(db.split(rows), has_b)]
@@ -675,7 +694,7 @@ class _LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = dgrad(code, dpre, [w], torch.empty(M, K, dtype=x2.dtype, device=x2.device)).reshape(xshape)
         dW, db = wgrad(code, dpre, x2, [w], bias=True, bias_params=ctx.bias_params) if has_b else (wgrad(code, dpre, x2, [w]), None)
-        return dx, dW, db, None, None
+        return dx, dW.view_as(w), db, None, None
 
 
 def linear_act(x, w, b, activation: str, drop_p: float = 0.0):

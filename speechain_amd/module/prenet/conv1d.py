@@ -32,7 +32,7 @@ class Conv1dEv(nn.Module):
 
     def forward_btc(self, x: torch.Tensor, drop_p: float = 0.0, residual=None) -> torch.Tensor:
         """(B, T, C_in) -> (B, T, C_out): the layout the HIP path works in."""
-        return Fn.linear(shifted_cat(Fn.to_compute(x), self.kernel_size), [self.gemm_weight()], [self.conv_lyr.bias], drop_p=drop_p,
+        return Fn.linear(shifted_cat(Fn.to_compute(x), self.kernel_size), [self.conv_lyr.weight], [self.conv_lyr.bias], drop_p=drop_p,
                          residual=residual)
 
     def forward(self, feat: torch.Tensor) -> torch.Tensor:

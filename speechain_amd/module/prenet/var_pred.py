@@ -75,7 +75,7 @@ class Conv1dVarPredictor(Module):
         i = 0
         while i < len(mods):
             conv, ln = mods[i], mods[i + 2]
-            x = Fn.linear_act(shifted_cat(x, conv.kernel_size), conv.gemm_weight(), conv.conv_lyr.bias, "ReLU", 0.0)
+            x = Fn.linear_act(shifted_cat(x, conv.kernel_size), conv.conv_lyr.weight, conv.conv_lyr.bias, "ReLU", 0.0)
             x = Fn.layer_norm(x, ln.weight, ln.bias, ln.eps)
             i += 3
             if i < len(mods) and isinstance(mods[i], torch.nn.Dropout):

@@ -44,5 +44,7 @@ class PositionwiseFeedForward(Module):
                           self.activation_name, p, _res_drop, res)
         # conv type: each layer is a GEMM over the time-shifted concatenation of its input
         cin, cout = self.in_layer, self.out_layer
-        h = Fn.linear_act(shifted_cat(x, cin.kernel_size), cin.gemm_weight(), cin.conv_lyr.bias, self.activation_name, p)
-        return Fn.linear(shifted_cat(h, cout.kernel_size), [cout.gemm_weight()], [cout.conv_lyr.bias], drop_p=_res_drop, residual=res)
+        # (the Conv1d weights go in as they are, (out, in, k): functional reads them as the (out, k * in) matrices of these products and
+        # writes their gradients back in the weights' own layout -- cached casts, gradient-bucket slots, the grouped wgrad launch)
+        h = Fn.linear_act(shifted_cat(x, cin.kernel_size), cin.conv_lyr.weight, cin.conv_lyr.bias, self.activation_name, p)
+        return Fn.linear(shifted_cat(h, cout.kernel_size), [cout.conv_lyr.weight], [cout.conv_lyr.bias], drop_p=_res_drop, residual=res)

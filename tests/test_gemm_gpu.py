@@ -227,7 +227,7 @@ def _grouped(problems, tile):
 
     n = len(problems)
     outs = []
-    for dz, x, want_db in problems:
+    for dz, x, want_db, *_ in problems:
         dW = torch.full((dz.size(1), x.size(1)), float("nan"), device="cuda")
         db = torch.full((dz.size(1),), float("nan"), device="cuda") if want_db else None
         outs.append((dW, db))
@@ -238,7 +238,8 @@ def _grouped(problems, tile):
              arr(ctypes.c_void_p, [p[1].data_ptr() for p in problems]), arr(ctypes.c_void_p, [o[0].data_ptr() for o in outs]),
              arr(ctypes.c_void_p, [o[1].data_ptr() if o[1] is not None else 0 for o in outs]),
              n_out, n_in, arr(ctypes.c_int, [p[0].size(0) for p in problems]), arr(ctypes.c_longlong, [p[0].stride(0) for p in problems]),
-             arr(ctypes.c_longlong, [p[1].stride(0) for p in problems]), tile, ws.data_ptr(), ws.numel(), stream())
+             arr(ctypes.c_longlong, [p[1].stride(0) for p in problems]), arr(ctypes.c_int, [p[3] if len(p) > 3 else 1 for p in problems]), tile,
+             ws.data_ptr(), ws.numel(), stream())
     return outs
 
 
@@ -258,9 +259,15 @@ def test_grouped_weight_gradients(tile):
     # more units than one table-writer launch carries (56)
     for i in range(38):
         problems.append((_mk((64, 24), torch.bfloat16, 300 + i), _mk((64, 16), torch.bfloat16, 400 + i), i % 4 == 0))
+    # two im2col products of 'same' Conv1d layers (3 and 5 taps): dW comes back in the nn.Conv1d weight layout (out, in, k)
+    problems.append((_mk((160, 48), torch.bfloat16, 501), _mk((160, 3 * 40), torch.bfloat16, 502), True, 3))
+    problems.append((_mk((96, 264), torch.bfloat16, 503), _mk((96, 5 * 16), torch.bfloat16, 504), False, 5))
     outs = _grouped(problems, tile)
-    for (dz, x, want_db), (dW, db) in zip(problems, outs):
+    for (dz, x, want_db, *ck), (dW, db) in zip(problems, outs):
         ref = dz.double().t() @ x.double()
+        if ck:  # GEMM column tap * C + c  ->  element (c, tap) of the Conv1d weight
+            k = ck[0]
+            ref = ref.view(ref.size(0), k, -1).permute(0, 2, 1).reshape(ref.size(0), -1)
         tok = dz.size(0)
         assert torch.allclose(dW.double(), ref, atol=2e-3 * math.sqrt(tok), rtol=1e-3), (dz.shape, x.shape, float((dW.double() - ref).abs().max()))
         if want_db:
