@@ -432,6 +432,7 @@ class ASRTrainStepWorkload:
 
 # ---- BASELINE configs[4]: FastSpeech2 train step -----------------------------------------------------
 TTS_SAMPLES, TTS_FRAMES, TTS_TOKENS, TTS_VOCAB = 163584, 640, 128, 75
+TTS_DROPOUT = (0.2, 0.5)  # trmf_dropout, conv_dropout of the recipe (tests set (0, 0) to compare replayed and eager steps)
 
 
 def tts_recipe_conf(dropout_trf=0.2, dropout_conv=0.5):
@@ -474,8 +475,9 @@ def synth_tts(seed: int, device, nb: int = BATCH):
 class TTSTrainStepWorkload:
     """FastSpeech2 train step from waveforms: frontend (mel + energy) -> three global normalisations -> encoder -> variance predictors ->
     length regulation -> decoder -> feat_pred + Conv1d postnet -> five-term loss -> backward -> clip 1.0 + Adam (Noam, warm-up 6000).
-    Eager launches (no hipGraph yet: the normalisations' running statistics and the duration arithmetic are host-sequenced), weight
-    gradients through the grouped launch, clip + Adam in two launches over the flat buckets."""
+    The head (frontend, normalisations with their running statistics, frame counts, per-token targets) runs eagerly; the rest of forward +
+    backward is one hipGraph and clip + Adam (two launches over the flat buckets) another (one rank; several ranks run eagerly with the
+    hook-launched bucket all-reduces).  Weight gradients through the grouped launch."""
 
     dtype = "bf16"
     name = ("FastSpeech2 train step (4enc/4dec d384 h2 conv-ffn1536 k3, predictors 256, postnet 256x4, bf16) from 32x7.4s@22.05kHz "
@@ -491,7 +493,7 @@ class TTSTrainStepWorkload:
         Fn.set_compute_dtype(torch.bfloat16)
         Fn.set_attention_probs(False)
         torch.manual_seed(0)
-        self.model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf()).to(device).train()
+        self.model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf(*TTS_DROPOUT)).to(device).train()
         for p in self.model.parameters():
             if p.dim() > 1:
                 torch.nn.init.xavier_normal_(p)
@@ -504,21 +506,54 @@ class TTSTrainStepWorkload:
         self.batch = synth_tts(seed, device)
         self.nstep, self.world = 0, world
         self.ev, self.flops, self.launch_flops, self.launch_kernels = [], 0.0, [], []
+        self.targets, self.g_body, self.g_tail, self.loss = None, None, None, None
+        self.use_graph = os.environ.get("BENCH_NO_GRAPH", "0") != "1"
+
+    def _body(self):
+        from speechain_amd import functional as Fn
+
+        Fn.DropoutState.advance()
+        Fn.weights.refresh()
+        self.reducer.zero_grad()
+        text, text_len = self.batch[0], self.batch[1]
+        out = self.model(text, text_len, targets=self.targets)
+        out["loss"].backward()
+        self.reducer.settle()
+        return out["loss"].detach()
 
     def step(self, timed: bool, instrument: bool = False):
-        from speechain_amd import functional as Fn
         from speechain_amd._lib import lib
 
         self.nstep += 1
         self.lr.fill_(384 ** -0.5 * min(self.nstep ** -0.5, self.nstep * 6000 ** -1.5))
+        # head, eager: frontend (mel + energy), the three normalisations (their running statistics are re-created on every call), frame counts per
+        # token, per-token pitch / energy targets -> the static inputs of the captured body
+        tg = self.model.prepare(*self.batch[2:], epoch=1)
+        if self.targets is None:
+            self.targets = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tg.items()}
+        else:
+            with torch.no_grad():
+                for k, v in tg.items():
+                    if torch.is_tensor(v):
+                        self.targets[k].copy_(v)
+        graph = self.use_graph and not instrument and self.nstep > 3 and not self.reducer.multi
+        if graph and self.g_body is None:
+            torch.cuda.synchronize()
+            self.g_body = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
+                self.loss = self._body()
+            self.g_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
+                self.opt.step()
+            torch.cuda.synchronize()
+        if graph:
+            self.g_body.replay()
+            self.g_tail.replay()
+            return self.loss
         if instrument:
             lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev, "sc_wgrad_grouped": self.ev}
             lib.flop_log, lib.kernel_log = [], []
-        Fn.DropoutState.advance()
-        Fn.weights.refresh()
-        self.reducer.zero_grad()
-        out = self.model(*self.batch, epoch=1)
-        out["loss"].backward()
+        loss = self._body()
         self.reducer.wait()
         self.opt.step()
         if instrument:
@@ -526,7 +561,7 @@ class TTSTrainStepWorkload:
             self.launch_flops += lib.flop_log
             self.launch_kernels += lib.kernel_log
             lib.timing = lib.flop_log = lib.kernel_log = None
-        return out["loss"].detach()
+        return loss
 
     roofline = None  # bound below: the GEMM roofline code of the ASR workload works on the same logs
 

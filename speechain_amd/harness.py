@@ -85,14 +85,22 @@ class TTSFastSpeech2(torch.nn.Module):
         self.feat_loss = LeastError(loss_type="L1")
         self.pitch_loss, self.energy_loss, self.duration_loss = (LeastError(loss_type="L2") for _ in range(3))
 
-    def forward(self, text, text_len, duration, duration_len, feat, feat_len, pitch, pitch_len, epoch: int = 1):
+    def prepare(self, duration, duration_len, feat, feat_len, pitch, pitch_len, epoch: int = 1):
+        """The weight-independent head of a step (frontend, normalisations, frame counts, per-token targets): see
+        FastSpeech2Decoder.prepare_targets.  Its result goes to ``forward(..., targets=...)``."""
+        with torch.no_grad():
+            return self.decoder.prepare_targets(duration=duration, duration_len=duration_len, pitch=pitch, pitch_len=pitch_len, feat=feat,
+                                                feat_len=feat_len, epoch=epoch, min_frame_num=0)
+
+    def forward(self, text, text_len, duration=None, duration_len=None, feat=None, feat_len=None, pitch=None, pitch_len=None, epoch: int = 1,
+                targets=None):
         """text (B, L) WITHOUT <sos/eos> (module_forward strips them, model/nar_tts.py:366-368); duration (B, L) in any unit (rescaled to
-        the frame count); feat (B, T_w, 1) waveforms; pitch (B, T) frame-level."""
+        the frame count); feat (B, T_w, 1) waveforms; pitch (B, T) frame-level -- or `targets` from :meth:`prepare`."""
         enc_text, enc_mask, _, _ = self.encoder(text=text, text_len=text_len)
         (before, after, pred_len, tgt_feat, tgt_feat_len, pred_pitch, tgt_pitch, tgt_pitch_len, pred_energy, tgt_energy, tgt_energy_len,
          pred_dur, pred_gate, used_dur, used_dur_len, _, _) = self.decoder(
             enc_text=enc_text, enc_text_mask=enc_mask, duration=duration, duration_len=duration_len, pitch=pitch, pitch_len=pitch_len,
-            feat=feat, feat_len=feat_len, epoch=epoch, min_frame_num=0)
+            feat=feat, feat_len=feat_len, epoch=epoch, min_frame_num=0, _targets=targets)
         terms = dict(feat_before=self.feat_loss(pred=before, tgt=tgt_feat, tgt_len=tgt_feat_len),
                      feat_after=self.feat_loss(pred=after, tgt=tgt_feat, tgt_len=tgt_feat_len),
                      pitch=self.pitch_loss(pred=pred_pitch, tgt=tgt_pitch, tgt_len=tgt_pitch_len),

@@ -81,13 +81,14 @@ class FastSpeech2Decoder(Module):
             x = x.reshape(B, T // r, r).mean(dim=-1)
         return x, torch.div(x_len, r, rounding_mode="floor").type(torch.long)
 
-    def forward(self, enc_text: torch.Tensor, enc_text_mask: torch.Tensor, duration: torch.Tensor = None, duration_len: torch.Tensor = None,
-                pitch: torch.Tensor = None, pitch_len: torch.Tensor = None, feat: torch.Tensor = None, feat_len: torch.Tensor = None,
-                energy: torch.Tensor = None, energy_len: torch.Tensor = None, spk_feat: torch.Tensor = None, spk_ids: torch.Tensor = None,
-                epoch: int = None, min_frame_num: int = None, max_frame_num: int = None, duration_alpha: torch.Tensor = None,
-                energy_alpha: torch.Tensor = None, pitch_alpha: torch.Tensor = None):
-        if spk_feat is not None or spk_ids is not None:
-            raise NotImplementedError("speechain_amd FastSpeech2Decoder: speaker features / ids are outside the accelerated path")
+    def prepare_targets(self, duration: torch.Tensor = None, duration_len: torch.Tensor = None, pitch: torch.Tensor = None,
+                        pitch_len: torch.Tensor = None, feat: torch.Tensor = None, feat_len: torch.Tensor = None, energy: torch.Tensor = None,
+                        energy_len: torch.Tensor = None, spk_ids: torch.Tensor = None, epoch: int = None, min_frame_num: int = None,
+                        max_frame_num: int = None, duration_alpha: torch.Tensor = None):
+        """The part of ``forward`` that depends on the batch only, not on the weights (nar_tts.py:266-340, :377-386, :404-407, :421-424):
+        frontend, the three normalisations (with their running statistics), frame grouping, the frame counts per token and the per-token
+        pitch / energy targets.  A trainer that captures the weight-dependent part into a hipGraph runs this eagerly (the normalisations
+        re-create their buffers on every call) and feeds the result to ``forward(..., _targets=...)``."""
         if feat is not None:
             if feat.size(-1) == 1:
                 assert hasattr(self, "feat_frontend"), \
@@ -104,9 +105,35 @@ class FastSpeech2Decoder(Module):
             if hasattr(self, "energy_normalize"):
                 energy, energy_len = self.energy_normalize(energy, energy_len, group_ids=spk_ids, epoch=epoch)
             energy, energy_len = self._reduce(energy, energy_len, False)
+        used_duration = used_duration_len = None
+        if duration is not None:
+            # ground-truth durations (seconds or any unit), rescaled to the utterance's number of frames (nar_tts.py:377-386)
+            used_duration = self.proc_duration(duration / duration.sum(dim=-1, keepdims=True) * feat_len.unsqueeze(-1),
+                                               min_frame_num=min_frame_num, max_frame_num=max_frame_num, duration_alpha=duration_alpha)
+            used_duration_len = duration_len
+            if pitch is not None:
+                pitch, pitch_len = self.average_scalar_by_duration(pitch, used_duration, used_duration_len)
+            if energy is not None:
+                energy, energy_len = self.average_scalar_by_duration(energy, used_duration, used_duration_len)
+        return dict(feat=feat, feat_len=feat_len, pitch=pitch, pitch_len=pitch_len, energy=energy, energy_len=energy_len,
+                    used_duration=used_duration, used_duration_len=used_duration_len)
+
+    def forward(self, enc_text: torch.Tensor, enc_text_mask: torch.Tensor, duration: torch.Tensor = None, duration_len: torch.Tensor = None,
+                pitch: torch.Tensor = None, pitch_len: torch.Tensor = None, feat: torch.Tensor = None, feat_len: torch.Tensor = None,
+                energy: torch.Tensor = None, energy_len: torch.Tensor = None, spk_feat: torch.Tensor = None, spk_ids: torch.Tensor = None,
+                epoch: int = None, min_frame_num: int = None, max_frame_num: int = None, duration_alpha: torch.Tensor = None,
+                energy_alpha: torch.Tensor = None, pitch_alpha: torch.Tensor = None, _targets: Dict = None):
+        if spk_feat is not None or spk_ids is not None:
+            raise NotImplementedError("speechain_amd FastSpeech2Decoder: speaker features / ids are outside the accelerated path")
+        tg = _targets if _targets is not None else self.prepare_targets(
+            duration=duration, duration_len=duration_len, pitch=pitch, pitch_len=pitch_len, feat=feat, feat_len=feat_len, energy=energy,
+            energy_len=energy_len, spk_ids=spk_ids, epoch=epoch, min_frame_num=min_frame_num, max_frame_num=max_frame_num,
+            duration_alpha=duration_alpha)
+        feat, feat_len, pitch, pitch_len, energy, energy_len = (tg[k] for k in ("feat", "feat_len", "pitch", "pitch_len", "energy", "energy_len"))
+        used_duration, used_duration_len = tg["used_duration"], tg["used_duration_len"]
         if self.training:
-            assert energy is not None and energy_len is not None and pitch is not None and pitch_len is not None and duration is not None \
-                and duration_len is not None, "During training, please give the ground-truth of energy, pitch, and duration."
+            assert energy is not None and energy_len is not None and pitch is not None and pitch_len is not None and used_duration is not None \
+                and used_duration_len is not None, "During training, please give the ground-truth of energy, pitch, and duration."
 
         outs = self.duration_predictor(enc_text, make_len_from_mask(enc_text_mask))
         if len(outs) == 2:
@@ -115,12 +142,7 @@ class FastSpeech2Decoder(Module):
             pred_duration, enc_text_len, pred_duration_gate = outs
         else:
             raise RuntimeError
-        if duration is not None:
-            # ground-truth durations (seconds or any unit), rescaled to the utterance's number of frames (nar_tts.py:377-386)
-            used_duration = self.proc_duration(duration / duration.sum(dim=-1, keepdims=True) * feat_len.unsqueeze(-1),
-                                               min_frame_num=min_frame_num, max_frame_num=max_frame_num, duration_alpha=duration_alpha)
-            used_duration_len = duration_len
-        else:
+        if used_duration is None:  # inference without ground-truth durations: the predictor's (nar_tts.py:387-402)
             pd = pred_duration.float()
             if pred_duration_gate is not None:
                 pd = pd.masked_fill(pred_duration_gate > 0, 0.0)
@@ -128,17 +150,17 @@ class FastSpeech2Decoder(Module):
                                                duration_alpha=duration_alpha)
             used_duration_len = enc_text_len
             used_duration = used_duration.masked_fill(~make_mask_from_len(enc_text_len, max_len=used_duration.size(1), return_3d=False), 0.0)
+            if pitch is not None:
+                pitch, pitch_len = self.average_scalar_by_duration(pitch, used_duration, used_duration_len)
+            if energy is not None:
+                energy, energy_len = self.average_scalar_by_duration(energy, used_duration, used_duration_len)
 
         pred_pitch, enc_text_len = self.pitch_predictor(enc_text, enc_text_len)
-        if pitch is not None:
-            pitch, pitch_len = self.average_scalar_by_duration(pitch, used_duration, used_duration_len)
         used_pitch = pitch if self.training else pred_pitch
         if not self.training and pitch_alpha is not None:
             used_pitch = used_pitch * pitch_alpha
         emb_pitch = self.pitch_predictor.emb_pred_scalar(used_pitch)
         pred_energy, enc_text_len = self.energy_predictor(enc_text, enc_text_len)
-        if energy is not None:
-            energy, energy_len = self.average_scalar_by_duration(energy, used_duration, used_duration_len)
         used_energy = energy if self.training else pred_energy
         if not self.training and energy_alpha is not None:
             used_energy = used_energy * energy_alpha

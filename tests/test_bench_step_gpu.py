@@ -100,3 +100,30 @@ def test_piecewise_replayed_step_equals_eager_step():
         if d > 5e-2 * ne + 1e-5 * total:
             bad[k] = (d, ne)
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+
+
+def test_tts_replayed_step_equals_eager_step():
+    """bench.py --workload tts_train_step: the FastSpeech2 step whose weight-dependent part is replayed from a hipGraph follows the same loss
+    curve as the eager step (dropout off; six steps incl. the Adam updates, so a stale weight copy or an unsettled gradient would show)."""
+    from speechain_amd import functional as Fn
+
+    bench = _bench()
+    bench.TTS_DROPOUT = (0.0, 0.0)
+    bench.TTSTrainStepWorkload.roofline = bench.ASRTrainStepWorkload.roofline
+    curves = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        Fn.DropoutState.reset(77)
+        Fn.weights.invalidate()
+        wl = bench.TTSTrainStepWorkload(torch.device("cuda", 0), 0, 1)
+        wl.use_graph = use_graph
+        curves.append([float(wl.step(False)) for _ in range(7)])
+        torch.cuda.synchronize()
+        assert (wl.g_body is not None) == use_graph
+        del wl
+        Fn.GradSinks.clear()
+        torch.cuda.empty_cache()
+    eager, replayed = curves
+    assert eager[0] > eager[-1], eager  # it trains
+    for a, b in zip(eager, replayed):
+        assert abs(a - b) <= 3e-3 * abs(a), (eager, replayed)
