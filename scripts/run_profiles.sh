@@ -1,11 +1,26 @@
-# produces the rocprofv3 summaries copied into profiles/ (run through gpurun from the repo root)
-set -e
+#!/bin/bash
+# Produces everything scripts/collect_profiles.py copies into profiles/ for one round (run through gpurun from the repo root, ONE call):
+# the bench lines (train step with both prenets, frontend, FastSpeech2), the rocprofv3 kernel statistics of the three workloads, and the
+# FETCH_SIZE / WRITE_SIZE passes (counters in their own runs, --kernel-trace only, as the MI355X guide prescribes).
 R=${GRAFT_REPO_ROOT:-$PWD}
-cd /tmp && export TMPDIR=/tmp
+O=$R/gpurun_out/prof
+mkdir -p $O
 cd $R
-mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/frontend -- python bench.py --workload frontend --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/prof/frontend_bench.json 2> gpurun_out/prof/frontend.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/train -- python bench.py --steps 20 --warmup 6 --no-cpu-baseline > gpurun_out/prof/train_bench.json 2> gpurun_out/prof/train.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/frontend_fetch -- python bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/prof/frontend_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/frontend_write -- python bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> gpurun_out/prof/frontend_write.err
-ls -R gpurun_out/prof | head -40
+echo "== bench lines"
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py --no-cpu-baseline --prenet-dims 512,512 > $O/bench_p512.json 2> $O/bench_p512.err
+python3 bench.py --workload frontend > $O/bench_frontend.json 2> $O/bench_frontend.err
+python3 bench.py --workload tts_train_step > $O/bench_tts.json 2> $O/bench_tts.err
+cd /tmp && export TMPDIR=/tmp
+echo "== kernel statistics"
+rm -rf $O/train $O/frontend $O/tts $O/train_fetch $O/train_write $O/frontend_fetch $O/frontend_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 $R/bench.py --steps 20 --warmup 6 --no-cpu-baseline > $O/train_bench.json 2> $O/train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/frontend -- python3 $R/bench.py --workload frontend --steps 30 --warmup 5 --no-cpu-baseline > $O/frontend_bench.json 2> $O/frontend.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tts -- python3 $R/bench.py --workload tts_train_step --steps 20 --warmup 6 --no-cpu-baseline > $O/tts_bench.json 2> $O/tts.err
+echo "== counters"
+export BENCH_NO_GRAPH=1 BENCH_NO_PREFETCH=1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/train_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/train_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/train_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/train_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/frontend_fetch -- python3 $R/bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/frontend_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/frontend_write -- python3 $R/bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/frontend_write.err
+ls $O

@@ -1452,8 +1452,8 @@ int launch(K kernel, const GemmArgs& a, int nbatch, hipStream_t stream, const ch
 static thread_local int g_last_gemm_kernel = 0;
 static const char* const kGemmKernelNames[] = {
     "none",
-    "gemm_bf16_nt_dma_kernel<2, 2, 2, 2>",
-    "gemm_bf16_nt_dma_kernel<2, 4, 4, 0>",
+    "gemm_bf16_nt_dma_kernel<2, 2, 2, 2, false>",
+    "gemm_bf16_nt_dma_kernel<2, 4, 4, 0, false>",
     "gemm_bf16_kernel<false, false>",
     "gemm_bf16_kernel<false, true>",
     "gemm_bf16_kernel<true, false>",
@@ -1462,8 +1462,8 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_kernel<true, true> (split-K) + splitk_reduce_kernel",
     "gemm_bf16_tn_dma_splitk_kernel + splitk_reduce_kernel",
     "gemm_bf16_kernel (split-K, other layout) + splitk_reduce_kernel",
-    "gemm_bf16_nt_dma_kernel<2, 2, 1, 2>",
-    "gemm_bf16_nt_dma_kernel<2, 1, 1, 1>",
+    "gemm_bf16_nt_dma_kernel<2, 2, 1, 2, false>",
+    "gemm_bf16_nt_dma_kernel<2, 1, 1, 1, false>",
     "wgrad_grouped_kernel<2, 4, 4>",
     "wgrad_grouped_kernel<2, 2, 2>",
 };

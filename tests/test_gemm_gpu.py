@@ -43,7 +43,7 @@ def test_few_tile_products_on_64x64_tiles(M, N, K, res):
     C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
     Fn.gemm(Fn.BF16, Fn._p(A), Fn._p(B), Fn._p(C), M, N, K, K, K, N, bias=bias, aux=Fn._p(R) if res else None, ldaux=N, aux_mode=1 if res else 0)
     from speechain_amd._lib import lib
-    assert lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode() == "gemm_bf16_nt_dma_kernel<2, 1, 1, 1>"
+    assert lib.load().sc_gemm_kernel_name(lib.load().sc_gemm_last_kernel()).decode() == "gemm_bf16_nt_dma_kernel<2, 1, 1, 1, false>"
     ref = A.double() @ B.double().t() + bias.double() + (R.double() if res else 0)
     assert torch.allclose(C.double(), ref, **_tol(torch.bfloat16, K)), float((C.double() - ref).abs().max())
 
