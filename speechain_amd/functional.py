@@ -256,18 +256,18 @@ class _WeightCache:
                         assert p.is_contiguous() and p.dtype == torch.float32
                         if k[1] == "vec":  # a bias: one row of p.numel() columns at element offset r of the concatenation
                             rows, cols = 1, p.numel()
-                            rec = (p.data_ptr(), buf.data_ptr() + esz * r, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
+                            rec = (p.data_ptr(), buf.data_ptr() + esz * r, 0, rows, cols, cols, 0, tile0, (cols + 63) // 64)
                             r += cols
                         else:
                             rows, cols = p.size(0), p.numel() // p.size(0)
                             if transposed:
-                                rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, buf.size(1), tile0, (cols + 31) // 32)
+                                rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, buf.size(1), tile0, (cols + 63) // 64)
                             else:
-                                rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 31) // 32)
+                                rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 63) // 64)
                             r += rows
                         conv_k = p.size(2) if (p.dim() == 3 and k[1] != "vec") else 1
                         recs.append(struct.pack("<QQQiiqqiiii", *rec, conv_k, 0))
-                        tile0 += ((cols + 31) // 32) * ((rows + 31) // 32)
+                        tile0 += ((cols + 63) // 64) * ((rows + 63) // 64)
                 dev = ents[0][1][1].device
                 cur = (sig, torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev), len(recs), tile0)
                 self._desc[code] = cur
