@@ -1520,7 +1520,8 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
-      if (big >= 160 && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4, 0>(a, nb, stream); }
+      static const long long bigmin = [] { const char* e = getenv("SC_GEMM_BIG_MIN"); return e ? atoll(e) : 200LL; }();  // (A/B knob; 7968 x 1536 x 512, 192 tiles of 256 x 256: 27.4 us, as 756 tiles of 128 x 128: 26.3 us)
+      if (big >= bigmin && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4, 0>(a, nb, stream); }
       // Very few tiles (the decoder's M = 2016, N = 512 products: 64 tiles of 128 x 128, 128 of 64 x 128): 64 x 64 tiles, two waves each,
       // put a workgroup on every CU.  Step-level A/B (40 steps, alternating): 12.35 / 12.36 / 12.55 ms with them vs 12.60 / 12.61 / 12.69
       // without; thresholds of 80, 128 and 192 tiles measure the same (12.53 .. 12.64 on another box), 256 hurts (12.99).
