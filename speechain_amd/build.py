@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libspeechain_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-Rpass-analysis=kernel-resource-usage"]
+         "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("SC_EXTRA_HIPCC_FLAGS", "").split()  # (e.g. -DSC_ATTN_TIMING: probes)
 _SCRATCH = re.compile(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", re.S)
 
 

@@ -563,6 +563,373 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(AttnArgs p, const unsi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, "key on the lane": one workgroup of NW waves per (batch, head); wave w owns keys 32 w .. 32 w + 31 and keeps their
+// K and V rows as MFMA B fragments and their dK^T, dV^T (head dims x keys) as accumulators for the whole kernel.  NW = 4 (one
+// wave per SIMD) for up to 128 keys, NW = 8 (two waves per SIMD: one wave's exp / hash / select work runs beside the other's
+// matrix products) for up to 256.  The workgroup sweeps the queries 64 at a time (two 32-query blocks):
+//   S' = Q K^T - lse / scale and dP' = dO V^T - delta (1 - p_drop): the row constants are the INITIAL accumulators, so that
+//        p = exp2(c1 S') needs no subtraction and no row maximum; a -inf constant switches a row (query >= Tq, all-masked
+//        row) or a key (padding mask, causal) off;
+//   the accumulators hold one key per lane and 16 queries per 32 x 32 block, which is the B-operand layout of the next two
+//        products: dV^T += dO^T P~ and dK^T += Q^T dS take P~ and dS straight from registers (the A operands are transposing
+//        reads of the one Q / dO image in LDS, in the matching query order);
+//   only dS crosses LDS, once, as a [key][query] image (8-byte stores of four consecutive queries) for
+//        dQ^T = K^T dS^T (head dims x queries): wave w takes (head-dim block w & 1, query block (w >> 1) & 1) and, with eight
+//        waves, the key half w >> 2; the upper half's partial sum crosses LDS and is added by its partner after the next
+//        barrier the loop has anyway; 8-byte stores per register quad.
+// Dropout: the mask word of a key pair is hashed once, by the even lane for the even query row and by the odd lane for
+// the odd row, exchanged with one DPP move and put in (row, row + 1) order by one v_perm.  The factors scale and
+// 1 / (1 - p_drop) are applied to the sums at the end (dS' = p sel, dS = keep scale dS'; P~' = p or 0, dV = keep sum).
+// Q, dO and O of the next 64 queries are fetched into registers before the current ones are used (two LDS stages): two
+// barriers per 64 queries.  Every global load of the prologue is in flight before the first one is waited for.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): the loads and stores in flight stay in flight
+#define KL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// -DSC_ATTN_TIMING (instrumented builds only): workgroup 0 records s_memtime at the phase boundaries of every round, per wave;
+// read back with sc_attention_debug_read (not part of the ABI)
+#ifdef SC_ATTN_TIMING
+__device__ long long sc_attn_probe[8 * 8 * 8];
+#define KL_PROBE(round, point)                                                                         \
+  do {                                                                                                 \
+    if (blockIdx.x == 0 && lane == 0 && (round) < 8) sc_attn_probe[(wid * 8 + (round)) * 8 + (point)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define KL_PROBE(round, point) do {} while (0)
+#endif
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, const unsigned short* Og) {
+  constexpr int NK = 32 * NW;    // keys the workgroup covers
+  constexpr int NT = 64 * NW;    // threads
+  constexpr int SPT = 512 / NT;  // 16-byte chunks of a 64 x 64 stage per thread and matrix
+  constexpr int TPR = 8 / SPT;   // threads per stage row
+  constexpr int KPT = NK * 8 / NT;  // 16-byte chunks of the K image per thread (4)
+  constexpr int NKS = NK / 16 / (NW / 4);  // k-steps of one wave's dQ product (8)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* Kimg = (unsigned short*)smem_raw;  // [NK][72]
+  unsigned short* Timg = Kimg + NK * LDR;            // [NK][72]   dS'^T
+  unsigned short* QT = Timg + NK * LDR;              // [2][64][72]
+  unsigned short* DT = QT + 2 * 64 * LDR;            // [2][64][72]
+  float* rowc = (float*)(DT + 2 * 64 * LDR);         // [2][2][64]: -lse / scale, -delta (1 - p_drop)
+  float* red = rowc + 256;                           // [4][4][64][4] partial dQ^T of the upper key half (NW = 8)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int z = blockIdx.x, b = z / p.H, hd = z - b * p.H;
+  const unsigned short* Qg = p.Q + b * p.q_b + hd * DH;
+  const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
+  const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
+  const unsigned short* dOg = p.dO + b * p.o_b + hd * DH;
+  const unsigned short* Ogh = Og + b * p.o_b + hd * DH;
+  const int wkey0 = wid * 32;
+  const bool wave_on = wkey0 < p.Tk;  // a wave without keys only takes part in the dQ product
+  KL_PROBE(7, 0);
+  const float inv_scale = 1.f / p.scale, c1 = p.scale * 1.4426950408889634f, unkeep = 1.f - p.drop_p;
+
+  // ---- this thread's share of a 64-query stage: row tid / TPR, 16-byte chunks (tid % TPR) + TPR i ----
+  const int sr = tid / TPR, sc = tid % TPR;
+  uint4 rq[SPT], rd[SPT], ro[SPT];
+  float rlse;
+  auto fetch = [&](int q0) {  // loads only: their latency is covered by the round in between
+    const int q = q0 + sr;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) rq[i] = rd[i] = ro[i] = make_uint4(0, 0, 0, 0);
+    rlse = -INFINITY;
+    if (q < p.Tq) {
+#pragma unroll
+      for (int i = 0; i < SPT; ++i) {
+        rq[i] = *(const uint4*)(Qg + (long long)q * p.ldq + (sc + TPR * i) * 8);
+        rd[i] = *(const uint4*)(dOg + (long long)q * p.ldo + (sc + TPR * i) * 8);
+        ro[i] = *(const uint4*)(Ogh + (long long)q * p.ldo + (sc + TPR * i) * 8);
+      }
+      rlse = p.LSE[(long long)z * p.Tq + q];
+    }
+  };
+  auto stash = [&](int buf) {
+    float dot = 0.f;  // delta = rowsum(dO * O): this thread's elements; the row's other threads are the neighbouring lanes
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+      const unsigned wd[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w}, wo[4] = {ro[i].x, ro[i].y, ro[i].z, ro[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dot += __uint_as_float(wd[j] << 16) * __uint_as_float(wo[j] << 16);
+        dot += __uint_as_float(wd[j] & 0xFFFF0000u) * __uint_as_float(wo[j] & 0xFFFF0000u);
+      }
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    if (TPR == 8) dot += __shfl_xor(dot, 4, 64);
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+      *(uint4*)(QT + (buf * 64 + sr) * LDR + (sc + TPR * i) * 8) = rq[i];
+      *(uint4*)(DT + (buf * 64 + sr) * LDR + (sc + TPR * i) * 8) = rd[i];
+    }
+    // (computed by every thread, so that the lse load is waited for on every path: left pending in most threads, it makes the
+    // compiler drain vmcnt -- the dQ stores included -- before the next fetch may overwrite the register)
+    const float nl = (rlse == -INFINITY) ? -INFINITY : -rlse * inv_scale;
+    asm volatile("" ::"v"(nl));
+    if (sc == 0) {
+      rowc[buf * 128 + sr] = nl;
+      rowc[buf * 128 + 64 + sr] = -dot * unkeep;
+    }
+  };
+
+  // ---- prologue: every load first (stage 0, the K image, this wave's V fragments, its mask bytes), then the LDS writes ----
+  fetch(0);
+  uint4 kreg[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int c = tid + i * NT, r = c >> 3, ch = c & 7;
+    kreg[i] = make_uint4(0, 0, 0, 0);
+    if (r < p.Tk) kreg[i] = *(const uint4*)(Kg + (long long)r * p.ldk + ch * 8);
+  }
+  bf16x8_t kf[4], vf[4];
+  const int key = wkey0 + li;
+  const int kc = min(key, p.Tk - 1);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8_t*)(Vg + (long long)kc * p.ldk + ks * 16 + h * 8);
+  const bool kvalid = key < p.Tk && (p.mask == nullptr || p.mask[b * p.mask_b + kc] != 0);
+  for (int c = tid; c < NK * 9; c += NT) ((uint4*)Timg)[c] = make_uint4(0, 0, 0, 0);  // keys of idle waves stay zero rows of dS'^T
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int c = tid + i * NT, r = c >> 3, ch = c & 7;
+    *(uint4*)(Kimg + r * LDR + ch * 8) = kreg[i];
+  }
+  stash(0);
+  const bool need_poison = !__all(kvalid);
+  const unsigned long long seed = DROP ? *p.seed : 0ull;
+  const unsigned thr = sc_drop_threshold(p.drop_p);
+  const int odd = li & 1;
+  // the word of (row r, row r + 1) in that order from this lane's hash x and the neighbour's y: even lanes take the low halves
+  // (x, y), odd lanes the high halves (y, x)
+  const unsigned wsel = odd ? 0x07060302u : 0x01000504u;
+  // pair index of (query row, key) = rowbase + lane term; the lane term carries the key pair, the odd lanes' +1 row and the
+  // upper lane half's +4 rows
+  const unsigned lterm = (unsigned)(key >> 1) + (unsigned)odd * (unsigned)(p.ldp >> 1) + (unsigned)h * (unsigned)(2 * p.ldp);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[d][r] = dv[d][r] = 0.f;
+
+  // nothing of the prologue may be left in flight: the compiler would wait for it INSIDE the loop, with counts that, from the second
+  // round on, drain the prefetched rows instead
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  KL_BARRIER();  // K image, stage 0
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_rowmajor(Kimg, LDR, key, ks * 16, lane);
+
+  const int g = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
+  const int ud = wid & 1, uq = (wid >> 1) & 1, ukh = wid >> 2;  // dQ unit of this wave: head-dim block, query block, key half
+  f32x16 dq_prev;  // (NW = 8, lower key half) the previous round's partial sum, completed after the next barrier
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq_prev[r] = 0.f;
+  auto store_dq = [&](const f32x16& acc, int q0) {
+    const int q = q0 + uq * 32 + li;
+    if (q < p.Tq) {
+      const float f = p.scale * p.drop_keep;
+      unsigned short* dQg = p.dQ + b * p.dq_b + hd * DH + (long long)q * p.lddq + ud * 32 + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned w0 = sc_f32_to_bf16(acc[4 * j] * f) | ((unsigned)sc_f32_to_bf16(acc[4 * j + 1] * f) << 16);
+        const unsigned w1 = sc_f32_to_bf16(acc[4 * j + 2] * f) | ((unsigned)sc_f32_to_bf16(acc[4 * j + 3] * f) << 16);
+        *(uint2*)(dQg + 8 * j) = make_uint2(w0, w1);
+      }
+    }
+  };
+  auto finish_prev = [&](int q0_prev) {  // lower key half: add the partner's partial sum of the previous round and store
+    float4* rp = (float4*)red + (ud * 2 + uq) * 256 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = rp[j * 64];
+      dq_prev[4 * j] += t.x; dq_prev[4 * j + 1] += t.y; dq_prev[4 * j + 2] += t.z; dq_prev[4 * j + 3] += t.w;
+    }
+    store_dq(dq_prev, q0_prev);
+  };
+
+  int buf = 0;
+  KL_PROBE(0, 7);
+  for (int q0 = 0; q0 < p.Tq; q0 += 64, buf ^= 1) {
+    KL_PROBE(q0 >> 6, 0);
+    fetch(q0 + 64);  // unconditionally (rows beyond Tq are zeros without a load), and stashed unconditionally below: a fetch that is
+                     // consumed on only some paths makes the compiler drain vmcnt at the top of the loop
+    if (q0 > 0) KL_BARRIER();  // stage `buf` is visible; every wave is done with the dS' image and the partial sums of the last round
+    KL_PROBE(q0 >> 6, 1);
+    if (NW == 8 && q0 > 0 && ukh == 0) finish_prev(q0 - 64);
+    const unsigned short* Qs = QT + buf * 64 * LDR;
+    const unsigned short* Ds = DT + buf * 64 * LDR;
+    const float* nlc = rowc + buf * 128;
+
+    if (wave_on) {
+#pragma unroll 1
+      for (int qb = 0; qb < 2; ++qb) {  // (a loop, not two copies: register pressure)
+        f32x16 s, dp;
+        float ndk[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 a = *(const float4*)(nlc + qb * 32 + 8 * j + 4 * h);
+          const float4 d4 = *(const float4*)(nlc + 64 + qb * 32 + 8 * j + 4 * h);
+          const float av[4] = {a.x, a.y, a.z, a.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            ndk[4 * j + i] = dvv[i];
+            s[4 * j + i] = av[i];
+            dp[4 * j + i] = dvv[i];
+          }
+        }
+        if (need_poison) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = kvalid ? s[r] : -INFINITY;
+        }
+        if (p.causal) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qg = q0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            s[r] = (key <= qg) ? s[r] : -INFINITY;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8_t aq = frag_rowmajor(Qs, LDR, qb * 32 + li, ks * 16, lane);
+          const bf16x8_t ad = frag_rowmajor(Ds, LDR, qb * 32 + li, ks * 16, lane);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+        }
+        // ---- P~', dS' as the B operands of the two key-side products ----
+        unsigned pw[8], dw[8];  // packed pairs (rows r, r + 1) of P~' and dS'
+        const unsigned long long rowbase0 = (p.offset + ((unsigned long long)z * p.Tq + q0 + qb * 32) * p.ldp) >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[r] * c1), p1 = __builtin_amdgcn_exp2f(s[r + 1] * c1);
+          float pd0 = p0, pd1 = p1, sel0 = dp[r], sel1 = dp[r + 1];
+          if (DROP) {
+            const unsigned long long rowbase = rowbase0 + (unsigned long long)(((r & 3) + 8 * (r >> 2)) * (p.ldp >> 1));
+            const unsigned hs = sc_rand_pair(seed, rowbase + lterm);
+            const unsigned gs = (unsigned)__builtin_amdgcn_update_dpp((int)hs, (int)hs, 0xB1, 0xF, 0xF, false);  // the neighbour lane's word
+            const unsigned w = __builtin_amdgcn_perm(hs, gs, wsel);
+            const bool d0 = (w & 0xFFFFu) < thr, d1 = (w >> 16) < thr;
+            pd0 = d0 ? 0.f : p0;
+            pd1 = d1 ? 0.f : p1;
+            sel0 = d0 ? ndk[r] : sel0;
+            sel1 = d1 ? ndk[r + 1] : sel1;
+          }
+          // (asm after the selects: left to itself the compiler converts first and selects the 16-bit halves afterwards.  Never asm
+          // on the v_exp result itself: the one wait state a transcendental's consumer needs is not inserted for inline asm)
+          if (DROP) pw[r >> 1] = cvt_pk_bf16(pd0, pd1);
+          else pw[r >> 1] = (unsigned)sc_f32_to_bf16(pd0) | ((unsigned)sc_f32_to_bf16(pd1) << 16);
+          dw[r >> 1] = cvt_pk_bf16(p0 * sel0, p1 * sel1);
+        }
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          pf[ss] = __builtin_bit_cast(bf16x8_t, make_uint4(pw[4 * ss], pw[4 * ss + 1], pw[4 * ss + 2], pw[4 * ss + 3]));
+          dsf[ss] = __builtin_bit_cast(bf16x8_t, make_uint4(dw[4 * ss], dw[4 * ss + 1], dw[4 * ss + 2], dw[4 * ss + 3]));
+        }
+        // ---- dV^T += dO^T P~', dK^T += Q^T dS': k-step ss covers queries 32 qb + 16 ss + 4 h + {0..3, 8..11} ----
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const int rbase = qb * 32 + 16 * ss + 4 * (g >> 1) + tq;
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int col = d * 32 + 16 * (g & 1) + 4 * tp;
+            const s16x4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Ds + rbase * LDR + col));
+            const s16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Ds + (rbase + 8) * LDR + col));
+            const s16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Qs + rbase * LDR + col));
+            const s16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Qs + (rbase + 8) * LDR + col));
+            const bf16x8_t ado = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8_t aqt = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7));
+            dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pf[ss], dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqt, dsf[ss], dk[d], 0, 0, 0);
+          }
+        }
+        // ---- dS'^T image: registers 4 j .. 4 j + 3 are queries 32 qb + 8 j + 4 h + 0..3 of this lane's key ----
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const uint4 w = __builtin_bit_cast(uint4, dsf[ss]);
+          unsigned short* trow = Timg + key * LDR + qb * 32 + 16 * ss + 4 * h;
+          *(uint2*)(trow) = make_uint2(w.x, w.y);
+          *(uint2*)(trow + 8) = make_uint2(w.z, w.w);
+        }
+      }
+    }
+    KL_PROBE(q0 >> 6, 2);
+    KL_BARRIER();  // the dS' image of this round is complete
+    KL_PROBE(q0 >> 6, 3);
+
+    // ---- dQ^T = K^T dS'^T for (head-dim block, query block, key half) of this wave: two chains of NKS / 2 products ----
+    {
+      f32x16 dq0, dq1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq0[r] = dq1[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKS; kk += 2) {
+        const int k0 = (ukh * NKS + kk) * 16;
+        const bf16x8_t a0 = frag_transposed(Kimg, LDR, ud * 32, k0, lane);
+        const bf16x8_t b0 = frag_transposed(Timg, LDR, uq * 32, k0, lane);
+        const bf16x8_t a1 = frag_transposed(Kimg, LDR, ud * 32, k0 + 16, lane);
+        const bf16x8_t b1 = frag_transposed(Timg, LDR, uq * 32, k0 + 16, lane);
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, dq1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq0[r] += dq1[r];
+      KL_PROBE(q0 >> 6, 4);
+      stash(buf ^ 1);  // before the dQ stores: waits for the fetched rows then never include those stores
+      KL_PROBE(q0 >> 6, 5);
+      if (NW == 4) {
+        store_dq(dq0, q0);
+      } else if (ukh == 1) {
+        float4* rp = (float4*)red + (ud * 2 + uq) * 256 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rp[j * 64] = make_float4(dq0[4 * j], dq0[4 * j + 1], dq0[4 * j + 2], dq0[4 * j + 3]);
+      } else {
+        dq_prev = dq0;
+      }
+    }
+  }
+  KL_BARRIER();  // every wave is done with the dS' image (it stages dK / dV below); the last round's partial sums are complete
+  if (NW == 8 && ukh == 0) finish_prev((p.Tq - 1) / 64 * 64);
+
+  // ---- dK, dV of this wave's keys: registers 4 j .. 4 j + 3 are head dims 32 d + 8 j + 4 h + 0..3.  Through the wave's own rows of
+  // the (now idle) dS' image, so that the stores are whole 128-byte rows instead of 16-byte pieces of 32 rows each ----
+  KL_PROBE(7, 1);
+  if (wave_on) {
+    const float fk = p.scale * p.drop_keep, fv = p.drop_keep;
+    unsigned short* stg = Timg + wkey0 * LDR;  // [32][72], this wave's
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const float f = m == 0 ? fk : fv;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const f32x16& acc = m == 0 ? dk[d] : dv[d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *(uint2*)(stg + li * LDR + d * 32 + 8 * j + 4 * h) =
+              make_uint2(cvt_pk_bf16(acc[4 * j] * f, acc[4 * j + 1] * f), cvt_pk_bf16(acc[4 * j + 2] * f, acc[4 * j + 3] * f));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own writes; nobody else touches these rows
+      unsigned short* dst = (m == 0 ? p.dK : p.dV) + b * p.dkv_b + hd * DH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3), kk = wkey0 + r;
+        const uint4 v = *(const uint4*)(stg + r * LDR + (lane & 7) * 8);
+        if (kk < p.Tk) *(uint4*)(dst + (long long)kk * p.lddk + (lane & 7) * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the second matrix overwrites the rows
+    }
+  }
+  KL_PROBE(7, 2);
+}
+#undef KL_BARRIER
+#undef KL_PROBE
+
 }  // namespace
 
 SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Tq, int Tk,
@@ -618,9 +985,30 @@ SC_API int sc_attention_bwd(const void* Q, const void* K, const void* V, const v
   a.seed = seed; a.offset = offset;
   a.dO = (const unsigned short*)dO; a.dQ = (unsigned short*)dQ; a.dK = (unsigned short*)dK; a.dV = (unsigned short*)dV;
   a.dq_b = dq_b; a.lddq = lddq; a.dkv_b = dkv_b; a.lddk = lddk;
+  const bool kl_ok = lddq % 4 == 0 && dq_b % 4 == 0 && lddk % 8 == 0 && dkv_b % 8 == 0 && (uintptr_t)dQ % 8 == 0 && (uintptr_t)dK % 16 == 0 &&
+                     (uintptr_t)dV % 16 == 0 && getenv("SC_ATTN_BWD_OLD") == nullptr;
+  if (kl_ok) {
+    const int nw = Tk > 128 ? 8 : 4;
+    const size_t smem = (size_t)(2 * 32 * nw + 4 * 64) * LDR * 2 + 4 * 64 * sizeof(float) + (nw == 8 ? 4 * 4 * 64 * 4 * sizeof(float) : 0);
+    const void* fn = nw == 8 ? (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<8, true> : (const void*)attn_bwd_kl_kernel<8, false>)
+                             : (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<4, true> : (const void*)attn_bwd_kl_kernel<4, false>);
+    SC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const unsigned short* Oc = (const unsigned short*)O;
+    void* kargs[] = {&a, &Oc};
+    SC_HIP(hipLaunchKernel(fn, dim3(B * H), dim3(64 * nw), kargs, smem, stream));
+    SC_LAUNCH_CHECK("attn_bwd_kl_kernel");
+    return SC_OK;
+  }
   const size_t smem = (size_t)(2 * 64 + 2 * TKMAX) * LDR * 2 + (size_t)2 * 64 * LDPB * 2 + 2 * 64 * sizeof(float);
   SC_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(512), smem, stream, a, (const unsigned short*)O);
   SC_LAUNCH_CHECK("attn_bwd_kernel");
   return SC_OK;
 }
+
+#ifdef SC_ATTN_TIMING
+SC_API int sc_attention_debug_read(long long* host, int n) {
+  SC_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(sc_attn_probe), (size_t)n * sizeof(long long)));
+  return SC_OK;
+}
+#endif

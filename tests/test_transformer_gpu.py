@@ -484,6 +484,47 @@ def test_streaming_attention_forward_through_the_c_abi(Tq, Tk, causal):
     assert float(out[2].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("Tq,Tk,causal", [(249, 249, False), (63, 249, False), (63, 63, True), (130, 130, True), (1, 5, False), (300, 64, False),
+                                          (70, 128, False), (200, 129, False), (64, 256, False), (33, 200, False)])
+def test_attention_backward_through_the_c_abi(Tq, Tk, causal):
+    """sc_attention_bwd (key-on-the-lane kernel; 32 or 64 keys per wave by Tk) on packed (B, T, H*64) bf16 buffers against torch
+    autograd in fp32 on the same bf16 values: dQ, dK, dV (bf16 outputs of sums over bf16-rounded P and dS: 2 % of the largest
+    element); ragged key masks, an utterance without visible keys (zero gradients), query counts that are not multiples of 64."""
+    from speechain_amd._lib import lib, stream
+
+    gen = torch.Generator().manual_seed(Tq * 1000 + Tk + 7)
+    B, H, dh = 3, 2, 64
+    q = torch.randn(B, Tq, H * dh, generator=gen).bfloat16().cuda()
+    k = torch.randn(B, Tk, H * dh, generator=gen).bfloat16().cuda()
+    v = torch.randn(B, Tk, H * dh, generator=gen).bfloat16().cuda()
+    do = torch.randn(B, Tq, H * dh, generator=gen).bfloat16().cuda()
+    lens = torch.tensor([Tk, max(1, Tk // 2 + 1), 0]).cuda()
+    m8 = (torch.arange(Tk, device="cuda")[None, :] < lens[:, None]).to(torch.uint8)[:, None, :].contiguous()
+    out = torch.empty(B, Tq, H * dh, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H, Tq, device="cuda")
+    scale = 1.0 / math.sqrt(dh)
+    lib.call("sc_attention_fwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(lse), B, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0),
+             k.stride(1), out.stride(0), out.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, stream())
+    dq, dk, dv = (torch.full_like(t, float("nan")) for t in (q, k, v))
+    lib.call("sc_attention_bwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(do), Fn._p(lse), Fn._p(dq), Fn._p(dk), Fn._p(dv), B, H, Tq, Tk,
+             q.stride(0), q.stride(1), k.stride(0), k.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1), dk.stride(0),
+             dk.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, stream())
+    qf, kf, vf = (t.float().view(B, -1, H, dh).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
+    s_ = (qf @ kf.transpose(-1, -2)) * scale
+    ok = m8.bool()[:, :, None, :].expand(B, H, Tq, Tk).clone()
+    if causal:
+        ok &= (torch.arange(Tk, device="cuda")[None, :] <= torch.arange(Tq, device="cuda")[:, None])[None, None]
+    pr = torch.nan_to_num(torch.softmax(s_.masked_fill(~ok, float("-inf")), -1), nan=0.0)
+    ref = (pr @ vf).transpose(1, 2).reshape(B, Tq, H * dh)
+    gq, gk, gv = torch.autograd.grad((ref * do.float()).sum(), [qf, kf, vf])
+    for name, got, want in (("dq", dq, gq), ("dk", dk, gk), ("dv", dv, gv)):
+        want = want.transpose(1, 2).reshape(got.shape)
+        assert bool(torch.isfinite(got.float()).all()), name
+        tol = 2e-2 * float(want.abs().max()) + 1e-3
+        assert float((got.float() - want).abs().max()) <= tol, (name, float((got.float() - want).abs().max()), tol)
+    assert float(dq[2].float().abs().max()) == 0.0 and float(dk[2].float().abs().max()) == 0.0 and float(dv[2].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_embedding_table_gradient_vs_torch(dtype):
     """sc_embedding_bwd (one wave per position, the first holder of an id sums its rows in position order) against nn.Embedding's
