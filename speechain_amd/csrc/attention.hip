@@ -60,6 +60,15 @@ __device__ __forceinline__ bf16x8_t frag_transposed(const unsigned short* tile, 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// two f32 -> packed bf16 pair in ONE instruction.  Inline asm, so (a) never feed it the result of a transcendental (v_exp, v_rcp ...)
+// directly: the wait state such a result needs before its first use is not inserted for asm; (b) it pins the order "select, then
+// convert" that the compiler otherwise turns into "convert each, select 16-bit halves, v_perm".
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // rows [r0, r0+nrows) x 64 columns of a strided bf16 matrix -> LDS tile with row stride LDR; rows >= valid are zero
 __device__ __forceinline__ void load_rows(unsigned short* tile, const unsigned short* src, long long ld, int r0, int nrows,
                                           int valid, int tid, int nthreads) {
@@ -216,21 +225,46 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_kernel(AttnArgs p) {
 // Dropout indices, the LSE definition (natural log) and the zero output of an all-masked row are those of attn_fwd_kernel,
 // so attn_bwd_kernel consumes either forward.
 // ---------------------------------------------------------------------------------------------------------------
+// -DSC_ATTN_TIMING (instrumented builds only): workgroup 0 records s_memtime at phase boundaries, per wave; read back with
+// sc_attention_debug_read (not part of the ABI)
+#ifdef SC_ATTN_TIMING
+__device__ long long sc_attn_probe[8 * 8 * 8];
+#define AT_PROBE(round, point)                                                                                            \
+  do {                                                                                                                    \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (round) < 8)                                                   \
+      sc_attn_probe[(wid * 8 + (round)) * 8 + (point)] = __builtin_readcyclecounter();                                     \
+  } while (0)
+#else
+#define AT_PROBE(round, point) do {} while (0)
+#endif
 typedef __attribute__((address_space(1))) const void* at_gptr_t;
 typedef __attribute__((address_space(3))) void* at_lptr_t;
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   constexpr int KT = 64, STAGES = 3, TILE = KT * DH, STAGE_ELEMS = 2 * TILE;  // K tile + V tile per stage (16 KB)
   extern __shared__ __attribute__((aligned(1024))) unsigned short dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, li = lane & 31;
-  const int z = blockIdx.y, b = z / p.H, hd = z - b * p.H;
-  const int qg = blockIdx.x * 128 + wid * 32 + li;  // this lane's query
+  // workgroups are dealt to the 8 XCDs round-robin by linear id: the query tiles of one (batch, head) are mapped to ids 8 apart, i.e.
+  // to ONE XCD and to consecutive slots of it, so that the head's K and V come out of that XCD's L2 from the second tile on
+  int z = blockIdx.y, qt = blockIdx.x;
+  {
+    const int nq = gridDim.x, nz = gridDim.y;
+    if (nq > 1 && (nz & 7) == 0) {
+      const int lin = blockIdx.x + nq * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+      z = (slot / nq) * 8 + xcd;
+      qt = slot % nq;
+    }
+  }
+  const int b = z / p.H, hd = z - b * p.H;
+  const int qg = qt * 128 + wid * 32 + li;  // this lane's query
   const int qc = min(qg, p.Tq - 1);
   const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
   const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
   const int nt = (p.Tk + KT - 1) / KT;
+  AT_PROBE(7, 0);
 
   // DMA sources: a granule is 8 key rows x 128 B; wave w stages granules 2w, 2w+1 of K and of V.  Lane l fills LDS slot
   // (row l >> 3, chunk l & 7) from source chunk (l & 7) ^ (row & 7); rows beyond Tk are clamped (masked out below).
@@ -259,11 +293,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
     const int kk = t_ * KT + lane;
     return kk < p.Tk && (mrow == nullptr || mrow[min(kk, p.Tk - 1)] != 0);
   };
-  const float c1 = p.scale * 1.4426950408889634f;  // scores are kept in log2 units: p = exp2(c1 s - m)
-  const bool drop = p.drop_p > 0.f;
-  const unsigned long long seed = drop ? *p.seed : 0ull;
+  const float c1 = p.scale * 1.4426950408889634f;  // running maximum and sums are kept in log2 units: p = exp2(c1 s - m)
+  const unsigned long long seed = DROP ? *p.seed : 0ull;
   const unsigned thr = sc_drop_threshold(p.drop_p);
-  const unsigned long long idxq = p.offset + ((unsigned long long)z * p.Tq + qc) * p.ldp;
+  // pair index of this lane's (query, key 64 t + kb + 4 h), kb even: pairq + 32 t + kb / 2
+  const unsigned long long pairq = ((p.offset + ((unsigned long long)z * p.Tq + qc) * p.ldp) >> 1) + (unsigned)(2 * h);
+  const int qwave0 = qt * 128 + wid * 32;  // first query of the wave
 
   f32x16 o[2];
 #pragma unroll
@@ -276,17 +311,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   if (nt > 0) AT_ISSUE(0);
   if (nt > 1) AT_ISSUE(1);
   for (int t = 0; t < nt; ++t) {
+    AT_PROBE(t, 0);
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    AT_PROBE(t, 1);
     const bool kok_next = (t + 1 < nt) ? key_ok(t + 1) : false;
     if (t + 2 < nt) AT_ISSUE(t + 2);
     const unsigned short* ks_ = dsm + (t % STAGES) * STAGE_ELEMS;
     const unsigned short* vs_ = ks_ + TILE;
     // key validity of the tile as a 64-bit lane mask
-    unsigned long long bits = __ballot(kok);
+    const unsigned long long bits = __ballot(kok);
     kok = kok_next;
-    bits >>= 4 * h;  // register r of block j then is bit 32 j + (r & 3) + 8 (r >> 2)
 
     // ---- S^T = K Q^T: two 32-key blocks x 32 queries ----
     f32x16 s2[2];
@@ -301,50 +337,66 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
         s2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s2[j], 0, 0, 0);
       }
     }
-    // ---- online softmax for this lane's query ----
+    AT_PROBE(t, 2);
+    // ---- masks: only for a tile with an invisible key or one the causal diagonal runs through (wave-uniform test) ----
+    if (bits != ~0ull || (p.causal && t * KT + KT - 1 > qwave0)) {
+      const int dq = p.causal ? qg - t * KT - 4 * h : KT;  // register (j, r) is visible up to key index 32 j + (r & 3) + 8 (r >> 2) <= dq
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned wj = (unsigned)(bits >> (32 * j)) >> (4 * h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kb = (r & 3) + 8 * (r >> 2);
+          const bool ok = (wj & (1u << kb)) != 0u && 32 * j + kb <= dq;
+          s2[j][r] = ok ? s2[j][r] : -INFINITY;
+        }
+      }
+    }
+    // ---- online softmax for this lane's query (the maximum is taken over the raw scores: c1 > 0) ----
     float mloc = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kb = 32 * j + (r & 3) + 8 * (r >> 2);  // + 4 h: key inside the tile
-        bool ok = (bits >> kb) & 1ull;
-        if (p.causal) ok = ok && (t * KT + kb + 4 * h <= qg);
-        const float x = ok ? s2[j][r] * c1 : -INFINITY;
-        s2[j][r] = x;
-        mloc = fmaxf(mloc, x);
-      }
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s2[j][r]);
     {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
       mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // both halves: max over all 64 keys
     }
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
-    const float msub = (m_new == -INFINITY) ? 0.f : m_new;
+    const float m_new = fmaxf(m_run, mloc * c1);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    const float nmsub = (m_new == -INFINITY) ? 0.f : -m_new;
     float lsum = 0.f;
     bf16x8_t pf[4];  // P~^T operand: k-step ks = block ks >> 1, registers 8 (ks & 1) .. + 7
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      unsigned pw[8];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        float p0 = exp2f(s2[j][r] - msub), p1 = exp2f(s2[j][r + 1] - msub);  // exp2(-inf) = 0 for masked keys
+        // exp2(-inf) = 0 for masked keys.  The factor 1 / (1 - p_drop) of the kept ones is applied to the row at the end.
+        float p0 = __builtin_amdgcn_exp2f(fmaf(s2[j][r], c1, nmsub)), p1 = __builtin_amdgcn_exp2f(fmaf(s2[j][r + 1], c1, nmsub));
         lsum += p0 + p1;
-        if (drop) {
-          const int kb = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;  // even key: (kb, kb + 1) share one hash word
-          const unsigned hsh = sc_rand_pair(seed, (idxq + (unsigned long long)(t * KT + kb)) >> 1);
-          p0 = ((hsh & 0xFFFFu) < thr) ? 0.f : p0 * p.drop_keep;
-          p1 = ((hsh >> 16) < thr) ? 0.f : p1 * p.drop_keep;
+        if (DROP) {
+          const int kb = 32 * j + (r & 3) + 8 * (r >> 2);  // (+ 4 h) even key: (kb, kb + 1) share one hash word
+          const unsigned hsh = sc_rand_pair(seed, pairq + (unsigned)(t * (KT / 2) + kb / 2));
+          p0 = ((hsh & 0xFFFFu) < thr) ? 0.f : p0;
+          p1 = ((hsh >> 16) < thr) ? 0.f : p1;
+          pw[r >> 1] = cvt_pk_bf16(p0, p1);
+        } else {
+          pw[r >> 1] = (unsigned)sc_f32_to_bf16(p0) | ((unsigned)sc_f32_to_bf16(p1) << 16);
         }
-        const int ks = 2 * j + (r >> 3), e = r & 7;
-        pf[ks][e] = (__bf16)p0;
-        pf[ks][e + 1] = (__bf16)p1;
       }
+      pf[2 * j] = __builtin_bit_cast(bf16x8_t, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+      pf[2 * j + 1] = __builtin_bit_cast(bf16x8_t, make_uint4(pw[4], pw[5], pw[6], pw[7]));
+    }
     l_run = l_run * alpha + lsum;
     m_run = m_new;
+    if (__any(alpha != 1.f)) {  // (the running maximum of most rows settles in the first tiles)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+    }
+    AT_PROBE(t, 3);
     // ---- O^T += V^T P~^T: two 32-head-dim blocks; k-step ks covers keys 32 (ks >> 1) + 16 (ks & 1) + 4 h + {0..3, 8..11} ----
     {
       const int g = lane >> 4, ip = lane & 15, q = ip >> 2, pp = ip & 3;
@@ -365,12 +417,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
     }
   }
 #undef AT_ISSUE
+  AT_PROBE(7, 1);
 
   // ---- normalise and store: lane (query, half h) holds head dims 32 j + 8 (r >> 2) + 4 h + (r & 3) ----
   {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? p.drop_keep / l : 0.f;
     if (qg < p.Tq) {
       if (h == 0) p.LSE[(long long)z * p.Tq + qg] = l > 0.f ? (m_run + log2f(l)) * 0.6931471805599453f : -INFINITY;
       unsigned short* orow = p.O + b * p.o_b + hd * DH + (long long)qg * p.ldo;
@@ -384,6 +437,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
         }
     }
   }
+  AT_PROBE(7, 2);
 }
 
 // Backward: one 512-thread workgroup per (batch, head) sweeping its 64-query tiles.  K and V of the head stay in LDS; per
@@ -587,22 +641,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(AttnArgs p, const unsi
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier): the loads and stores in flight stay in flight
 #define KL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// -DSC_ATTN_TIMING (instrumented builds only): workgroup 0 records s_memtime at the phase boundaries of every round, per wave;
-// read back with sc_attention_debug_read (not part of the ABI)
-#ifdef SC_ATTN_TIMING
-__device__ long long sc_attn_probe[8 * 8 * 8];
-#define KL_PROBE(round, point)                                                                         \
-  do {                                                                                                 \
-    if (blockIdx.x == 0 && lane == 0 && (round) < 8) sc_attn_probe[(wid * 8 + (round)) * 8 + (point)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define KL_PROBE(round, point) do {} while (0)
-#endif
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+#define KL_PROBE(round, point) AT_PROBE(round, point)
 template <int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, const unsigned short* Og) {
   constexpr int NK = 32 * NW;    // keys the workgroup covers
@@ -929,6 +968,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
 }
 #undef KL_BARRIER
 #undef KL_PROBE
+#undef AT_PROBE
 
 }  // namespace
 
@@ -954,7 +994,8 @@ SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O
   a.seed = seed; a.offset = offset;
   if (stream_ok) {
     const size_t smem_s = (size_t)3 * 2 * 64 * DH * sizeof(unsigned short);  // three 16 KB stages
-    hipLaunchKernelGGL(attn_fwd_stream_kernel, dim3(sc_cdiv(Tq, 128), B * H), dim3(256), smem_s, stream, a);
+    if (drop_p > 0.f) hipLaunchKernelGGL(attn_fwd_stream_kernel<true>, dim3(sc_cdiv(Tq, 128), B * H), dim3(256), smem_s, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_stream_kernel<false>, dim3(sc_cdiv(Tq, 128), B * H), dim3(256), smem_s, stream, a);
     SC_LAUNCH_CHECK("attn_fwd_stream_kernel");
     return SC_OK;
   }
