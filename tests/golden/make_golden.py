@@ -633,6 +633,88 @@ def g10_tts():
         torch.Tensor.cuda = real_cuda
 
 
+# ---- G11 inference callers: beam search, CTC prefix scorer, prefix decoding ------------------------------------
+
+DECODE_SMALL = dict(d_model=32, num_heads=2, dec_layers=2, fdfwd_dim=64, vocab_size=23, activation="GELU")
+
+
+def g11_decode():
+    """beam_searching (infer_func/beam_search.py:106) driven by the reference's own ARASRDecoder (module/decoder/ar_asr.py) and a
+    TokenPostnet CTC head, three argument sets; CTCPrefixScorer (infer_func/ctc_decoding.py) on its own data for three steps.
+    ``speechain.model.lm`` (only a type annotation in beam_search.py:14,128) drags the whole model package in, whose dependencies
+    (editdistance, ruamel.yaml ...) are absent: a stub module with an empty ``LM`` class stands in for the import."""
+    lm = types.ModuleType("speechain.model.lm")
+    lm.LM = type("LM", (), {})
+    sys.modules.setdefault("speechain.model", types.ModuleType("speechain.model"))
+    sys.modules["speechain.model.lm"] = lm
+    from speechain.infer_func.beam_search import beam_searching
+    from speechain.infer_func.ctc_decoding import CTCPrefixScorer
+    from speechain.module.decoder.ar_asr import ARASRDecoder
+
+    c = DECODE_SMALL
+    d, V = c["d_model"], c["vocab_size"]
+    g = torch.Generator().manual_seed(1111)
+    dec = ARASRDecoder(vocab_size=V, embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=d)),
+                       decoder=dict(type="transformer.decoder.TransformerDecoder",
+                                    conf=dict(num_heads=c["num_heads"], num_layers=c["dec_layers"], fdfwd_dim=c["fdfwd_dim"],
+                                              fdfwd_activation=c["activation"], posenc_dropout=0.0, att_dropout=0.0, fdfwd_dropout=0.0,
+                                              res_dropout=0.0, emb_scale=False, posenc_maxlen=100)))
+    ctc_layer = TokenPostnet(input_size=d, vocab_size=V)
+    sd = seeded_state(dec, 111, scale=0.35)
+    sd_ctc = seeded_state(ctc_layer, 112, scale=0.5)
+    with torch.no_grad():
+        dec.postnet.linear.bias[V - 1] += 1.5  # <sos/eos> likely enough for some hypotheses to end before the length limit
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    dec.eval()
+    ctc_layer.eval()
+    B, T = 3, 14
+    enc = torch.randn(B, T, d, generator=g)
+    enc_len = torch.tensor([14, 11, 8])
+    mask = make_mask_from_len(enc_len)
+    out = dict(enc=enc, enc_len=enc_len)
+    out.update({f"sd.decoder.{k}": v for k, v in sd.items() if not k.endswith("posenc.posenc")})
+    out.update({f"sd.ctc_layer.{k}": v for k, v in sd_ctc.items()})
+    cases = dict(a=dict(beam_size=4, min_f2t_ratio=1.5),
+                 b=dict(beam_size=4, min_f2t_ratio=-8, ctc_weight=0.3, temperature=1.3, length_penalty=1.2, ctc_temperature=1.1),
+                 c=dict(beam_size=3, min_f2t_ratio=2.0, eos_filtering=True, eos_threshold=1.2),
+                 d=dict(beam_size=2, min_f2t_ratio=-9, ctc_weight=0.5))
+    with torch.no_grad():
+        for name, kw in cases.items():
+            res = beam_searching(enc_feat=enc.clone(), enc_feat_mask=mask.clone(), asr_decode_fn=dec, ctc_decode_fn=ctc_layer,
+                                 vocab_size=V, sos_eos=V - 1, padding_idx=0, **kw)
+            for k, v in res.items():
+                out[f"{name}.{k}"] = v
+        # prefix logits of one fixed batch of prefixes (what a cached decode step must reproduce position by position)
+        text = torch.randint(1, V - 1, (B, 7), generator=g)
+        text[:, 0] = V - 1
+        text_len = torch.tensor([7, 5, 3])
+        for i, l in enumerate(text_len):
+            text[i, l:] = 0
+        out.update(pref_text=text, pref_text_len=text_len, pref_logits=dec(enc, mask, text, text_len)[0])
+        # CTCPrefixScorer alone: 2 sentences x 3 beams, 9 tokens, three steps with a fixed choice of parents and tokens
+        Bc, beam, Tc, Vc = 2, 3, 7, 9
+        x = torch.log_softmax(torch.randn(Bc, Tc, Vc, generator=g) * 1.5, dim=-1).repeat_interleave(beam, dim=0)
+        lens = torch.tensor([7, 7, 7, 5, 5, 5])
+        sc = CTCPrefixScorer(x=x.clone(), enc_lens=lens, batch_size=Bc, beam_size=beam, blank_index=0, eos_index=Vc - 1)
+        out.update(ctc_x=x, ctc_lens=lens)
+        gtext = torch.zeros(Bc * beam, 0, dtype=torch.long)
+        state = None
+        picks = [(torch.tensor([0, 0, 1, 3, 4, 4]), torch.tensor([3, 5, 2, 1, 4, 7])),
+                 (torch.tensor([2, 0, 1, 5, 3, 3]), torch.tensor([5, 6, 2, 4, 4, 1])),
+                 (torch.tensor([1, 1, 0, 4, 5, 3]), torch.tensor([1, 5, 7, 2, 6, 6]))]
+        for step, (beam_idx, tokens) in enumerate(picks):
+            psi, state = sc.forward_step(gtext, state)
+            out[f"ctc_psi{step}"] = psi
+            gtext = torch.cat([gtext[beam_idx], tokens[:, None]], dim=1)
+            token_idx = tokens.view(Bc, beam) + (torch.arange(beam) * Vc)[None, :]
+            state = sc.permute_mem(state, beam_idx, token_idx)
+            out[f"ctc_r{step}"], out[f"ctc_psimem{step}"] = state[0], state[1][:, 0]
+            out[f"ctc_beam_idx{step}"], out[f"ctc_tokens{step}"] = beam_idx, tokens
+        psi, _ = sc.forward_step(gtext, state)
+        out["ctc_psi3"] = psi
+    save("g11_decode", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
