@@ -277,6 +277,32 @@ int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
                      const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
                      const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
 
+/* ---- cached-key/value decoding (csrc/decode.hip): the inference callers of SURVEY.md row f3 --------------------------------
+ * Replaces, inside speechain/infer_func/beam_search.py:325-333 + :518-521, the re-run of the whole decoder on the whole prefix at
+ * every step and the re-ordering of per-row tensors by beam_idx.
+ *
+ * sc_beam_table_update: table_out[n][t] = table_in[beam_idx[n]][t] for t < pos (beam_idx NULL: identity), table_out[n][pos] = n;
+ *   (N, Tmax) int32 tables, two distinct buffers.  table[n][t] names the cache row whose slot t holds position t of hypothesis n.
+ * sc_attention_decode: one step of causal self-attention, heads of 64; dtype 0 = f32, 1 = bf16.  qkv (N, >= 3 d), row stride ldqkv:
+ *   this step's [q | k | v]; cache (N, Tmax, 2 d) [k | v]: slot (n, pos) is written, slots (table[n][t], t), t < pos, are read;
+ *   out (N, d), row stride ldo: softmax(scale q K^T) V per head (speechain/module/transformer/attention.py:88-106 on one query row). */
+int sc_beam_table_update(const int* table_in, int* table_out, const long long* beam_idx, int N, int Tmax, int pos, hipStream_t stream);
+int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache, const int* table, void* out, long long ldo, int N, int H,
+                        int Tmax, int pos, float scale, hipStream_t stream);
+
+/* CTC prefix scores for joint CTC / attention decoding (speechain/infer_func/ctc_decoding.py:76-196; Algorithm 2 of Watanabe et al.
+ * 2017).  x (B, T, V) f32 CTC log-probabilities, ONE copy per sentence: hypothesis row n belongs to sentence n / beam; enc_lens (B)
+ * int32; frames past an utterance count as certain blank (:49-57); "impossible" is the reference's finite -1e20.
+ *   sc_ctc_prefix_scores: psi (N = B * beam, V) for every candidate token of every row from the forward variables r_prev (T, 2, N) of
+ *     the rows' prefixes; last (N): last label of each prefix (unused when plen == 0); eos_frame (N) int32: frame whose
+ *     logaddexp(r_prev[.][0], r_prev[.][1]) is the row's <eos> score (:151-155); psi(., blank) = -1e20 (:158).  T <= 4096.
+ *   sc_ctc_prefix_state: r_new (T, 2, N), the forward variables of the surviving candidates -- new row n = prefix of row beam_idx[n]
+ *     extended by tokens[n] -- recomputed for those N pairs (the reference gathers them out of a (T, 2, N, V) tensor, :162-196). */
+int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev, const long long* last, float* psi,
+                         int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream);
+int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
+                        const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream);
+
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
  * lse[r] is kept for the backward pass, which writes dlogits = grow[r]/temperature * (softmax - (1-eps)*onehot - eps/V). */

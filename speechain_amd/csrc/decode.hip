@@ -1,0 +1,307 @@
+// Cached-key/value decoding for the autoregressive ASR decoder on gfx950.
+//
+// What it replaces in the reference (paths under /root/reference/): beam_searching (speechain/infer_func/beam_search.py:325-333) calls
+// the whole decoder on the whole growing prefix of every hypothesis at every step -- O(L^2) decoder passes per utterance -- and re-orders
+// the hypotheses by indexing every per-row tensor with beam_idx (:518-521).  Here a step feeds ONE position per hypothesis:
+//   * the keys and values of earlier positions stay where they were written, (row, position) slots of a (N, Tmax, 2 d) cache per layer;
+//   * a hypothesis is a list of slots: table[n][t] = the row whose slot t holds position t of hypothesis n.  Re-ordering the beams
+//     copies table rows (N x Tmax ints), never keys or values;
+//   * sc_attention_decode: one wave per (hypothesis, head) appends the step's key / value, scores the query against the history read
+//     through the table, and forms the context.  Byte-moving (each history row is read once per step): HBM / L2 bound.
+// Cross-attention needs none of this: its keys / values are per SENTENCE and the beams of a sentence are adjacent rows, so the
+// ordinary fused attention kernel runs with (sentences, beam) as (batch, queries).
+#include "sc_common.h"
+
+namespace {
+
+constexpr int DH = 64;  // head size (one lane per head dimension)
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  // dot of 64 contiguous elements with q (64 floats in LDS)
+  static __device__ __forceinline__ float dot64(const float* row, const float* q) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; j += 4) {
+      const float4 a = *(const float4*)(row + j);
+      const float4 b = *(const float4*)(q + j);
+      s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    return s;
+  }
+};
+template <> struct Elem<unsigned short> {
+  static __device__ __forceinline__ float ld(const unsigned short* p) { return sc_bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = sc_f32_to_bf16(v); }
+  static __device__ __forceinline__ float dot64(const unsigned short* row, const float* q) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; j += 8) {
+      const uint4 a = *(const uint4*)(row + j);
+      const float4 b0 = *(const float4*)(q + j), b1 = *(const float4*)(q + j + 4);
+      s += __uint_as_float(a.x << 16) * b0.x + __uint_as_float(a.x & 0xFFFF0000u) * b0.y;
+      s += __uint_as_float(a.y << 16) * b0.z + __uint_as_float(a.y & 0xFFFF0000u) * b0.w;
+      s += __uint_as_float(a.z << 16) * b1.x + __uint_as_float(a.z & 0xFFFF0000u) * b1.y;
+      s += __uint_as_float(a.w << 16) * b1.z + __uint_as_float(a.w & 0xFFFF0000u) * b1.w;
+    }
+    return s;
+  }
+};
+
+// table_out[n][t] = table_in[parent(n)][t] for t < pos, table_out[n][pos] = n.  grid (ceil(N / 4)); one wave per row.
+__global__ __launch_bounds__(256) void beam_table_kernel(const int* tin, int* tout, const long long* beam_idx, int N, int Tmax, int pos) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const long long par = beam_idx ? beam_idx[n] : n;
+  for (int t = lane; t < pos; t += 64) tout[(long long)n * Tmax + t] = tin[par * Tmax + t];
+  if (lane == 0) tout[(long long)n * Tmax + pos] = n;
+}
+
+// qkv: (N, 3 d) this step's projections [q | k | v]; cache: (N, Tmax, 2 d) [k | v]; table: (N, Tmax); out: (N, d).
+// grid (ceil(N H / 4)); one wave per (row, head); MAXP passes of 64 keys (Tmax <= 64 MAXP).
+template <typename T, int MAXP>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long long ldqkv, T* cache, const int* table, T* out, long long ldo,
+                                                          int N, int H, int Tmax, int pos, float scale) {
+  __shared__ __attribute__((aligned(16))) float qs[4][DH];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + w;
+  if (gw >= N * H) return;
+  const int n = gw / H, h = gw - n * H;
+  const int d = H * DH;
+  const T* row = qkv + (long long)n * ldqkv + h * DH;
+  const float q = Elem<T>::ld(row + lane), kn = Elem<T>::ld(row + d + lane), vn = Elem<T>::ld(row + 2 * d + lane);
+  // append this position: slot (n, pos)
+  T* slot = cache + ((long long)n * Tmax + pos) * (2 * d) + h * DH;
+  Elem<T>::st(slot + lane, kn);
+  Elem<T>::st(slot + d + lane, vn);
+  qs[w][lane] = q;
+  const float s_new = sc_wave_sum(q * kn) * scale;  // the new position's own score (its key is still in registers)
+  asm volatile("" ::: "memory");  // (the wave reads its own LDS row below; LDS operations of one wave complete in order)
+  const int* trow = table + (long long)n * Tmax;
+  float s[MAXP];
+  float m = s_new;
+#pragma unroll
+  for (int c = 0; c < MAXP; ++c) {
+    const int t = 64 * c + lane;
+    s[c] = -INFINITY;
+    if (64 * c < pos) {  // (wave-uniform)
+      if (t < pos) {
+        const T* kr = cache + ((long long)trow[t] * Tmax + t) * (2 * d) + h * DH;
+        s[c] = Elem<T>::dot64(kr, qs[w]) * scale;
+      }
+    }
+    if (t == pos) s[c] = s_new;
+    m = fmaxf(m, s[c]);
+  }
+  m = sc_wave_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXP; ++c) {
+    s[c] = __expf(s[c] - m);  // exp(-inf) = 0 beyond the history
+    l += s[c];
+  }
+  l = sc_wave_sum(l);
+  const float inv = 1.f / l;
+  // context: lane = head dimension; p_t is broadcast from the lane that scored key t
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXP; ++c) {
+    if (64 * c < pos) {
+      const int tend = min(pos, 64 * c + 64);
+      const float pc = s[c];
+      for (int t = 64 * c; t < tend; ++t) {
+        const int r = __builtin_amdgcn_readfirstlane(trow[t]);
+        const float p = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pc), t & 63));
+        acc = fmaf(p, Elem<T>::ld(cache + ((long long)r * Tmax + t) * (2 * d) + d + h * DH + lane), acc);
+      }
+    }
+  }
+  {
+    float pn = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXP; ++c)
+      if ((pos >> 6) == c) pn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s[c]), pos & 63));
+    acc = fmaf(pn, vn, acc);
+  }
+  Elem<T>::st(out + (long long)n * ldo + h * DH + lane, acc * inv);
+}
+
+}  // namespace
+
+// Ancestry table of a beam-search step (speechain/infer_func/beam_search.py:518-521 re-orders rows by beam_idx instead):
+// table_out[n][t] = table_in[beam_idx[n]][t] for t < pos (beam_idx NULL = identity), table_out[n][pos] = n.  Tables are (N, Tmax) int32.
+SC_API int sc_beam_table_update(const int* table_in, int* table_out, const long long* beam_idx, int N, int Tmax, int pos,
+                                hipStream_t stream) {
+  SC_CHECK_ARG(table_out && (table_in || pos == 0), "sc_beam_table_update: null pointer");
+  SC_CHECK_ARG(table_in != table_out, "sc_beam_table_update: the tables must be two buffers");
+  SC_CHECK_ARG(N >= 1 && Tmax >= 1 && pos >= 0 && pos < Tmax, "sc_beam_table_update: bad sizes N=%d Tmax=%d pos=%d", N, Tmax, pos);
+  hipLaunchKernelGGL(beam_table_kernel, dim3(sc_cdiv(N, 4)), dim3(256), 0, stream, table_in, table_out, beam_idx, N, Tmax, pos);
+  SC_LAUNCH_CHECK("beam_table_kernel");
+  return SC_OK;
+}
+
+// One decoding step of causal self-attention with cached keys / values (heads of 64).  dtype: 0 = f32, 1 = bf16.
+//   qkv   (N, >= 3 d) row stride ldqkv: this step's [q | k | v] projections of the N hypothesis rows;
+//   cache (N, Tmax, 2 d) [k | v]: slot (n, pos) is written here, slots (table[n][t], t), t < pos, are read;
+//   out   (N, d) row stride ldo: softmax(scale q K^T) V per head.
+SC_API int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache, const int* table, void* out, long long ldo, int N,
+                               int H, int Tmax, int pos, float scale, hipStream_t stream) {
+  SC_CHECK_ARG(qkv && cache && table && out, "sc_attention_decode: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_attention_decode: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(N >= 1 && H >= 1 && Tmax >= 1 && Tmax <= 512 && pos >= 0 && pos < Tmax, "sc_attention_decode: bad sizes N=%d H=%d Tmax=%d (<= 512) pos=%d",
+               N, H, Tmax, pos);
+  SC_CHECK_ARG((long long)N * H <= 0x7fffffffLL, "sc_attention_decode: too many (row, head) pairs");
+  const long long d = (long long)H * DH;
+  SC_CHECK_ARG(ldqkv >= 3 * d && ldo >= d, "sc_attention_decode: row strides too small");
+  SC_CHECK_ARG(((uintptr_t)cache | (uintptr_t)qkv) % 16 == 0 && ldqkv % 8 == 0, "sc_attention_decode: buffers must be 16-byte aligned");
+  const dim3 grid((unsigned)sc_cdiv(N * H, 4));
+  const int passes = pos / 64 + 1;
+#define SC_LAUNCH_DEC(T, P)                                                                                                          \
+  hipLaunchKernelGGL((attn_decode_kernel<T, P>), grid, dim3(256), 0, stream, (const T*)qkv, ldqkv, (T*)cache, table, (T*)out, ldo, N, H, \
+                     Tmax, pos, scale)
+  if (dtype == 0) {
+    if (passes <= 1) SC_LAUNCH_DEC(float, 1);
+    else if (passes <= 2) SC_LAUNCH_DEC(float, 2);
+    else if (passes <= 4) SC_LAUNCH_DEC(float, 4);
+    else SC_LAUNCH_DEC(float, 8);
+  } else {
+    if (passes <= 1) SC_LAUNCH_DEC(unsigned short, 1);
+    else if (passes <= 2) SC_LAUNCH_DEC(unsigned short, 2);
+    else if (passes <= 4) SC_LAUNCH_DEC(unsigned short, 4);
+    else SC_LAUNCH_DEC(unsigned short, 8);
+  }
+#undef SC_LAUNCH_DEC
+  SC_LAUNCH_CHECK("attn_decode_kernel");
+  return SC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CTC prefix scores (speechain/infer_func/ctc_decoding.py:76-160; Algorithm 2 of Watanabe et al. 2017).
+//
+// For hypothesis row n with prefix g and candidate token c (h = g + c), from the forward variables of g over the frames,
+// r_prev[t][0 | 1][n] = log prob of g ending in (its last label | blank) at frame t:
+//   r_sum[t] = logaddexp(r_prev[t][0], r_prev[t][1]);   phi[t] = (c == last label of g) ? r_prev[t][1] : r_sum[t]
+//   psi(n, c) = log( exp(r^n_{start-1}(h)) + sum_{t = start}^{T-1} exp(phi[t-1] + x[t][c]) ),  start = max(1, |g|),
+//   r^n_{start-1}(h) = x[0][c] for the empty prefix, impossible otherwise;  psi(n, <eos>) = r_sum[eos_frame[n]];  psi(n, blank) impossible.
+// "Impossible" is the reference's finite -1e20, so that sums of such terms stay finite exactly as they do there.  Frames past an
+// utterance count as certain blank (x = 0 for blank, -1e20 for labels, :49-57).
+//
+// The reference builds r(h) for ALL candidates -- a (T, 2, N, V) tensor per step -- because the next step needs the rows of the
+// candidates that survive.  psi itself needs no recursion (only phi, which belongs to g), so ctc_psi_kernel is a masked logsumexp over the
+// frames, one candidate per lane, x read once per sentence and frame with unit stride over the vocabulary; ctc_state_kernel then runs
+// the two-line recursion (:132-142) for the N surviving (parent row, token) pairs only.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr float CTC_IMPOSSIBLE = -1e20f;
+constexpr int CTC_TMAX = 4096;  // frames whose phi / r_sum fit the LDS row of a workgroup
+
+__device__ __forceinline__ float logaddexpf(float a, float b) {
+  const float m = fmaxf(a, b), d = fminf(a, b) - m;
+  return m + log1pf(__expf(d));
+}
+
+// grid (ceil(V / 256), N); thread = candidate c of row blockIdx.y.
+__global__ __launch_bounds__(256) void ctc_psi_kernel(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev,
+                                                      const long long* last, float* psi, int N, int T, int V, int beam, int plen,
+                                                      int blank, int eos) {
+  __shared__ float s_sum[CTC_TMAX], s_b[CTC_TMAX];
+  const int n = blockIdx.y, b = n / beam;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float r0 = r_prev[((long long)t * 2 + 0) * N + n], r1 = r_prev[((long long)t * 2 + 1) * N + n];
+    s_sum[t] = logaddexpf(r0, r1);
+    s_b[t] = r1;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= V) return;
+  const int len = enc_lens[b];
+  const long long lastc = plen > 0 ? last[n] : 0;  // (the reference takes token 0 for the empty prefix, :84)
+  const float* phi = (c == lastc) ? s_b : s_sum;
+  const float* xc = x + (long long)b * T * V + c;
+  const int start = plen > 1 ? plen : 1;
+  // running logsumexp: (m, s) with the first term r^n_{start-1}(h)
+  float m = (plen == 0) ? ((0 < len) ? xc[0] : (c == blank ? 0.f : CTC_IMPOSSIBLE)) : CTC_IMPOSSIBLE;
+  float s = 1.f;
+  for (int t = start; t < T; ++t) {
+    const float xl = (t < len) ? xc[(long long)t * V] : (c == blank ? 0.f : CTC_IMPOSSIBLE);
+    const float v = phi[t - 1] + xl;
+    if (v > m) {
+      s = s * __expf(m - v) + 1.f;
+      m = v;
+    } else {
+      s += __expf(v - m);
+    }
+  }
+  float out = m + __logf(s);
+  if (c == eos) out = s_sum[eos_frame[n]];
+  if (c == blank) out = CTC_IMPOSSIBLE;
+  psi[(long long)n * V + c] = out;
+}
+
+// grid (ceil(N / 64)); thread = new row n: the forward variables of (parent row beam_idx[n]) + (token tokens[n]) over all frames.
+__global__ __launch_bounds__(64) void ctc_state_kernel(const float* x, const int* enc_lens, const float* r_prev, const long long* last,
+                                                       const long long* beam_idx, const long long* tokens, float* r_new, int N, int T, int V,
+                                                       int beam, int plen, int blank) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  const int par = (int)beam_idx[n], b = par / beam;
+  const long long c = tokens[n];
+  const int len = enc_lens[b];
+  const long long lastc = plen > 0 ? last[par] : 0;
+  const float* xc = x + (long long)b * T * V;
+  const int start = plen > 1 ? plen : 1;
+  float rn = CTC_IMPOSSIBLE, rb = CTC_IMPOSSIBLE;
+  for (int t = 0; t < start && t < T; ++t) {  // frames before the recursion starts (:102-117)
+    float v = CTC_IMPOSSIBLE;
+    if (t == 0 && plen == 0) v = (0 < len) ? xc[c] : (c == blank ? 0.f : CTC_IMPOSSIBLE);
+    r_new[((long long)t * 2 + 0) * N + n] = v;
+    r_new[((long long)t * 2 + 1) * N + n] = CTC_IMPOSSIBLE;
+    rn = v;
+    rb = CTC_IMPOSSIBLE;
+  }
+  for (int t = start; t < T; ++t) {
+    const float p0 = r_prev[((long long)(t - 1) * 2 + 0) * N + par], p1 = r_prev[((long long)(t - 1) * 2 + 1) * N + par];
+    const float phi = (c == lastc) ? p1 : logaddexpf(p0, p1);
+    const float xl = (t < len) ? xc[(long long)t * V + c] : (c == blank ? 0.f : CTC_IMPOSSIBLE);
+    const float xb = (t < len) ? xc[(long long)t * V + blank] : 0.f;
+    const float nn = logaddexpf(rn, phi) + xl;
+    const float nb = logaddexpf(rn, rb) + xb;
+    rn = nn;
+    rb = nb;
+    r_new[((long long)t * 2 + 0) * N + n] = rn;
+    r_new[((long long)t * 2 + 1) * N + n] = rb;
+  }
+}
+
+}  // namespace
+
+// psi (N, V) of every candidate of every hypothesis row.  x (B, T, V) f32 log-probabilities, one copy per sentence (row n belongs to
+// sentence n / beam); enc_lens (B); eos_frame (N): the frame whose r_sum is the <eos> score of a row; r_prev (T, 2, N); last (N): the last
+// label of each prefix (ignored when plen == 0); plen: the prefix length without <sos>.
+SC_API int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev, const long long* last,
+                                float* psi, int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream) {
+  SC_CHECK_ARG(x && enc_lens && eos_frame && r_prev && psi && (last || plen == 0), "sc_ctc_prefix_scores: null pointer");
+  SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && T <= CTC_TMAX && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
+                   (long long)B * beam <= 65535, "sc_ctc_prefix_scores: bad sizes B=%d beam=%d T=%d (<= %d) V=%d plen=%d", B, beam, T, CTC_TMAX, V, plen);
+  hipLaunchKernelGGL(ctc_psi_kernel, dim3(sc_cdiv(V, 256), B * beam), dim3(256), 0, stream, x, enc_lens, eos_frame, r_prev, last, psi,
+                     B * beam, T, V, beam, plen, blank, eos);
+  SC_LAUNCH_CHECK("ctc_psi_kernel");
+  return SC_OK;
+}
+
+// r_new (T, 2, N): the forward variables of the surviving candidates, new row n = prefix of row beam_idx[n] extended by tokens[n]
+// (what ctc_decoding.py:162-196 gathers out of its (T, 2, N, V) tensor).
+SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
+                               const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream) {
+  SC_CHECK_ARG(x && enc_lens && r_prev && beam_idx && tokens && r_new && (last || plen == 0), "sc_ctc_prefix_state: null pointer");
+  SC_CHECK_ARG(r_prev != r_new, "sc_ctc_prefix_state: r_prev and r_new must be two buffers");
+  SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && V >= 1 && plen >= 0 && blank >= 0 && blank < V, "sc_ctc_prefix_state: bad sizes");
+  hipLaunchKernelGGL(ctc_state_kernel, dim3(sc_cdiv(B * beam, 64)), dim3(64), 0, stream, x, enc_lens, r_prev, last, beam_idx, tokens, r_new,
+                     B * beam, T, V, beam, plen, blank);
+  SC_LAUNCH_CHECK("ctc_state_kernel");
+  return SC_OK;
+}

@@ -1084,7 +1084,8 @@ class _AttnFused(torch.autograd.Function):
 def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, scale, drop_p):
     same = kv_buf is None or kv_buf is q_buf
     Tk = (q_buf if same else kv_buf).size(1)
-    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and Tk <= 256
+    # (the fused backward kernel holds the keys of a head in LDS: at most 256; the streaming forward takes any number)
+    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and (Tk <= 256 or not torch.is_grad_enabled())
             and q_buf.stride(1) % 8 == 0 and (same or kv_buf.stride(1) % 8 == 0)):
         out = _AttnFused.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
                                float(drop_p))
@@ -1535,3 +1536,61 @@ def avg_by_duration(frame_scalar: torch.Tensor, duration: torch.Tensor) -> torch
     out = torch.empty(d.shape, dtype=torch.float32, device=f.device)
     lib.call("sc_avg_by_duration", _p(f), _p(d), _p(out), f.size(0), d.size(1), f.size(1), stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cached-key/value decoding (inference; csrc/decode.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def beam_table_update(table_in: Optional[torch.Tensor], table_out: torch.Tensor, beam_idx: Optional[torch.Tensor], pos: int):
+    """table_out[n, :pos] = table_in[beam_idx[n], :pos] (identity without beam_idx), table_out[n, pos] = n; (N, Tmax) int32."""
+    require_gpu(table_out, "beam_table_update")
+    N, Tmax = table_out.shape
+    lib.call("sc_beam_table_update", _p(table_in), _p(table_out), _p(beam_idx), N, Tmax, int(pos), stream())
+
+
+def attention_decode(qkv: torch.Tensor, cache: torch.Tensor, table: torch.Tensor, pos: int, num_heads: int, scale: float) -> torch.Tensor:
+    """One step of causal self-attention over cached keys / values: qkv (N, 3 d) this step's projections, cache (N, Tmax, 2 d) (slot
+    (n, pos) is written), table (N, Tmax) int32 ancestry.  Returns the (N, d) context.  Heads of 64 only."""
+    require_gpu(qkv, "attention_decode")
+    N, d = qkv.size(0), qkv.size(1) // 3
+    if d // num_heads != 64:
+        raise NotImplementedError(f"speechain_amd: cached decoding is built for heads of 64 (got d_model={d}, num_heads={num_heads})")
+    assert qkv.is_contiguous() and cache.is_contiguous() and cache.dtype == qkv.dtype and cache.shape[0] == N and cache.shape[2] == 2 * d
+    out = torch.empty(N, d, dtype=qkv.dtype, device=qkv.device)
+    lib.call("sc_attention_decode", dcode(qkv), _p(qkv), qkv.stride(0), _p(cache), _p(table), _p(out), out.stride(0), N, num_heads,
+             cache.size(1), int(pos), float(scale), stream())
+    return out
+
+
+def ctc_prefix_init(x: torch.Tensor, enc_lens: torch.Tensor, beam: int, blank: int) -> torch.Tensor:
+    """Forward variables (T, 2, N) of the empty prefix: only blanks so far (ctc_decoding.py:88-99).  x (B, T, V) f32."""
+    B, T, _ = x.shape
+    t = torch.arange(T, device=x.device)[None, :]
+    xb = torch.where(t < enc_lens[:, None], x[:, :, blank], torch.zeros((), device=x.device))  # past the utterance: blank is certain
+    r = torch.full((T, 2, B * beam), -1e20, dtype=torch.float32, device=x.device)
+    r[:, 1] = torch.cumsum(xb, dim=1).t().repeat_interleave(beam, dim=1)
+    return r
+
+
+def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int) -> torch.Tensor:
+    """psi (N, V) of every candidate token of every hypothesis row (sc_ctc_prefix_scores); r_prev None = the empty prefix."""
+    require_gpu(x, "ctc_prefix_scores")
+    B, T, V = x.shape
+    if r_prev is None:
+        r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
+    psi = torch.empty(B * beam, V, dtype=torch.float32, device=x.device)
+    lib.call("sc_ctc_prefix_scores", _p(x), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B, beam, T, V, int(plen),
+             int(blank), int(eos), stream())
+    return psi
+
+
+def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int) -> torch.Tensor:
+    """Forward variables (T, 2, N) of the rows that continue row beam_idx[n] with tokens[n] (sc_ctc_prefix_state)."""
+    B, T, V = x.shape
+    if r_prev is None:
+        r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
+    r_new = torch.empty(T, 2, B * beam, dtype=torch.float32, device=x.device)
+    lib.call("sc_ctc_prefix_state", _p(x), _p(enc_lens), _p(r_prev.contiguous()), _p(last), _p(beam_idx.contiguous()), _p(tokens), _p(r_new),
+             B, beam, T, V, int(plen), int(blank), stream())
+    return r_new

@@ -1,0 +1,218 @@
+"""``beam_searching``, drop-in for ``speechain.infer_func.beam_search.beam_searching`` (speechain/infer_func/beam_search.py:106-550):
+same arguments, same result dictionary (``hypo_text``, ``hypo_text_len``, ``feat_token_len_ratio``, ``hypo_text_confid``), same
+selection rules -- 2 x beam candidates per sentence, <sos/eos> candidates of the first ``beam`` ranks close a hypothesis, the n-best list
+with its length-penalised scores and early stop (:21-103), padding of finished sentences, the length limit ``feat_maxlen / min_f2t_ratio``.
+
+What differs underneath:
+  * a decode function that offers ``start_decoding`` / ``forward_step`` (``speechain_amd.module.decoder.ar_asr.ARASRDecoder``) is fed
+    ONE token per hypothesis and step against cached keys / values (``csrc/decode.hip``); the reference re-runs the decoder on the whole
+    prefix (:325-333).  Any other callable is used exactly as the reference uses it;
+  * the encoder output is not repeated per beam (:258-274): the beams of a sentence are adjacent rows and never leave it;
+  * the CTC prefix scores come from ``sc_ctc_prefix_scores`` (no (T, 2, N, V) tensor, see ``infer_func/ctc_decoding.py``);
+  * the step's bookkeeping reads ONE small device-to-host copy (the 2 x beam best candidates per sentence) where the reference reads a
+    scalar per candidate (``.item()``, :446-506); hypotheses live on the host as integer arrays.
+"""
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
+
+eps = 1e-20
+minus_inf = -1e20
+
+
+class BeamHypotheses:
+    """N-best list of one sentence (beam_search.py:21-103): ``add`` keeps the ``beam_size`` best length-normalised scores,
+    ``is_done`` tells whether no running hypothesis can still beat the worst kept one."""
+
+    def __init__(self, beam_size: int, max_length: int, length_penalty: float):
+        self.max_length = max_length - 1
+        self.beam_size = beam_size
+        self.length_penalty = length_penalty
+        self.beams: List = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp, sum_logprobs: float):
+        score = sum_logprobs / ((len(hyp) + eps) ** self.length_penalty)
+        if len(self) < self.beam_size or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.beam_size:
+                ranked = sorted((s, i) for i, (s, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, curr_len: int = None) -> bool:
+        if len(self) < self.beam_size:
+            return False
+        if curr_len is None:
+            curr_len = self.max_length
+        return best_sum_logprobs / ((curr_len + eps) ** self.length_penalty) < self.worst_score
+
+
+def _first_output(out):
+    return out[0] if isinstance(out, (tuple, list)) else out
+
+
+def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_decode_fn: Callable, vocab_size: int, sos_eos: int = None,
+                   padding_idx: int = 0, beam_size: int = 1, min_f2t_ratio: float = 3.0, length_penalty: float = 1.0,
+                   temperature: float = 1.0, eos_filtering: bool = False, eos_threshold: float = 1.5, ctc_weight: float = 0.0,
+                   ctc_decode_fn: Optional[Callable] = None, ctc_temperature: float = 1.0, lm_weight: float = 0.2,
+                   lm_temperature: float = 1.0, lm_decode_fn: Optional[Callable] = None, lm_window_size: int = None,
+                   ilm_sub_weight: float = 0.0, sent_per_beam: int = 1) -> Dict[str, torch.Tensor]:
+    if sent_per_beam > 1:
+        raise NotImplementedError("Currently, sent_per_beam > 1 is not supported....")
+    assert 0.0 <= ctc_weight, f"ctc_weight should be a non-negative float number, but got ctc_weight={ctc_weight}!"
+    assert 0.0 <= lm_weight, f"lm_weight should be a non-negative float number, but got lm_weight={lm_weight}!"
+    assert 0.0 <= ilm_sub_weight, f"ilm_sub_weight should be a non-negative float number, but got ilm_sub_weight={ilm_sub_weight}!"
+    assert ctc_temperature > 0.0, f"ctc_temperature should be a positive float number, but got ctc_temperature={ctc_temperature}"
+    assert temperature > 0.0, f"temperature should be a positive float number, but got temperature={temperature}"
+    assert lm_temperature > 0.0, f"lm_temperature should be a positive float number, but got lm_temperature={lm_temperature}"
+    assert beam_size + 1 <= vocab_size, "beam_size cannot be larger than vocab_size - 1 (exclude <sos/eos>)!"
+
+    B, feat_maxlen = enc_feat.size(0), enc_feat.size(1)
+    dev = enc_feat.device
+    enc_feat_len = enc_feat_mask.squeeze(dim=1).sum(dim=-1)
+    hypo_maxlen = int(feat_maxlen / min_f2t_ratio) if min_f2t_ratio > 0 else int(-min_f2t_ratio)
+    if sos_eos is None:
+        sos_eos = vocab_size - 1
+    N, V = B * beam_size, vocab_size
+    cached = hasattr(asr_decode_fn, "start_decoding") and hasattr(asr_decode_fn, "forward_step")
+    use_lm = lm_decode_fn is not None and lm_weight > 0
+    need_prefix_on_device = (not cached) or use_lm
+
+    # ---- CTC scorer: one copy of the log-probabilities per sentence ----
+    ctc_scorer, ctc_memory = None, None
+    if ctc_decode_fn is not None and ctc_weight > 0:
+        with torch.no_grad():
+            ctc_logits = _first_output(ctc_decode_fn(enc_feat)).float().clone()
+        ctc_logits[:, :, sos_eos] = minus_inf  # CTC never predicts <sos/eos> (:279)
+        ctc_scorer = CTCPrefixScorer(x=torch.log_softmax(ctc_logits / ctc_temperature, dim=-1), enc_lens=enc_feat_len, batch_size=B,
+                                     beam_size=beam_size, blank_index=padding_idx, eos_index=sos_eos)
+
+    # ---- decoder state ----
+    if cached:
+        cache = asr_decode_fn.start_decoding(enc_feat, enc_feat_mask, beam_size, max(hypo_maxlen, 1))
+        enc_rep = mask_rep = None
+    if need_prefix_on_device:
+        enc_rep = enc_feat.repeat_interleave(beam_size, dim=0)
+        mask_rep = enc_feat_mask.repeat_interleave(beam_size, dim=0)
+
+    generated_hyps = [BeamHypotheses(beam_size, hypo_maxlen, length_penalty) for _ in range(B)]
+    done = [False] * B
+    beam_scores = torch.full((N,), float("-inf"), dtype=torch.float, device=dev)
+    beam_scores[::beam_size] = 0.0  # one live beam per sentence at the first step (:303-311)
+    text = np.full((N, 1), sos_eos, dtype=np.int64)  # the hypotheses, on the host
+    text_len = np.ones(N, dtype=np.int64)
+    last_tokens = torch.full((N,), sos_eos, dtype=torch.long, device=dev)
+    beam_idx_dev = None
+    slot_offset = (torch.arange(beam_size, device=dev) * V)[None, :]
+
+    while int(text_len.max()) < hypo_maxlen:
+        # ---- attention decoder: log-probabilities of the next token of every row ----
+        with torch.no_grad():
+            if cached:
+                logits = asr_decode_fn.forward_step(last_tokens, cache, beam_idx_dev)
+            else:
+                text_dev = torch.from_numpy(text).to(dev)
+                len_dev = torch.from_numpy(text_len).to(dev)
+                logits = _first_output(asr_decode_fn(enc_feat=enc_rep, enc_feat_mask=mask_rep, text=text_dev, text_len=len_dev))[:, -1, :]
+            next_token_scores = torch.log_softmax(logits.float() / temperature, dim=-1)
+            if ctc_scorer is not None:
+                next_token_scores[:, padding_idx] = minus_inf  # the blank is never a token (:339)
+                g = torch.from_numpy(text[:, 1:]).to(dev)
+                ctc_token_scores, ctc_memory = ctc_scorer.forward_step(g, ctc_memory)
+                next_token_scores = (1 - ctc_weight) * next_token_scores + ctc_weight * ctc_token_scores
+            if use_lm:  # (:348-398) a language model is called the way the reference calls it: on the (windowed) prefix
+                text_dev = torch.from_numpy(text).to(dev)
+                len_dev = torch.from_numpy(text_len).to(dev)
+                lm_text = text_dev if lm_window_size is None else text_dev[:, -lm_window_size:]
+                lm_len = len_dev if lm_window_size is None else torch.clamp(len_dev, max=lm_window_size)
+                lm_out = _first_output(lm_decode_fn(text=lm_text, text_len=lm_len))[:, -1, :]
+                next_token_scores = next_token_scores + lm_weight * torch.log_softmax(lm_out.float() / lm_temperature, dim=-1)
+                if ilm_sub_weight > 0:
+                    zeros = torch.zeros(N, 1, enc_feat.size(2), dtype=enc_feat.dtype, device=dev)
+                    ones = torch.ones(N, 1, 1, dtype=torch.bool, device=dev)
+                    ilm = _first_output(asr_decode_fn(enc_feat=zeros, enc_feat_mask=ones, text=lm_text, text_len=lm_len))[:, -1, :]
+                    next_token_scores = next_token_scores - ilm_sub_weight * torch.log_softmax(ilm.float(), dim=-1)
+            cand = (next_token_scores + beam_scores[:, None]).view(B, beam_size * V)
+            top_scores, top_ids = torch.topk(cand, 2 * beam_size, dim=1, largest=True, sorted=True)
+            fetch = [top_scores, top_ids.to(torch.float64)]
+            if eos_filtering:
+                others = next_token_scores.clone()
+                others[:, sos_eos] = float("-inf")
+                fetch += [next_token_scores[:, sos_eos].view(B, beam_size), others.max(dim=-1).values.view(B, beam_size)]
+            host = torch.cat([f.to(torch.float64) for f in fetch], dim=1).cpu().numpy()  # the step's one device-to-host copy
+        h_scores = host[:, :2 * beam_size].astype(np.float32)
+        h_ids = host[:, 2 * beam_size:4 * beam_size].astype(np.int64)
+        if eos_filtering:
+            h_eos = host[:, 4 * beam_size:5 * beam_size].astype(np.float32)
+            h_ref = host[:, 5 * beam_size:6 * beam_size].astype(np.float32)
+
+        # ---- selection (:423-509) ----
+        new_scores = np.zeros(N, dtype=np.float32)
+        new_tokens = np.full(N, padding_idx, dtype=np.int64)
+        new_parent = np.zeros(N, dtype=np.int64)
+        for b in range(B):
+            if done[b]:
+                continue  # padding tokens continuing row 0, score 0 (:428-431)
+            kept = 0
+            for rank in range(2 * beam_size):
+                flat, score = int(h_ids[b, rank]), h_scores[b, rank]
+                slot, token = flat // V, flat % V
+                row = b * beam_size + slot
+                if token == sos_eos:
+                    if rank >= beam_size:
+                        continue
+                    if eos_filtering and h_eos[b, slot] <= eos_threshold * h_ref[b, slot]:
+                        continue
+                    generated_hyps[b].add(torch.from_numpy(text[row, 1:].copy()), float(score))
+                else:
+                    n = b * beam_size + kept
+                    new_scores[n], new_tokens[n], new_parent[n] = score, token, row
+                    kept += 1
+                if kept == beam_size:
+                    break
+            done[b] = generated_hyps[b].is_done(best_sum_logprobs=float(h_scores[b].max()),
+                                                curr_len=int(text_len[b * beam_size:(b + 1) * beam_size].max()) - 1)
+        if all(done):
+            break
+
+        # ---- the next step's rows ----
+        beam_scores = torch.from_numpy(new_scores).to(dev)
+        last_tokens = torch.from_numpy(new_tokens).to(dev)
+        beam_idx_dev = torch.from_numpy(new_parent).to(dev)
+        text = np.concatenate([text[new_parent], new_tokens[:, None]], axis=1)
+        text_len = (text != padding_idx).sum(-1)
+        if need_prefix_on_device:
+            enc_rep, mask_rep = enc_rep[beam_idx_dev], mask_rep[beam_idx_dev]
+        if ctc_memory is not None:
+            ctc_memory = ctc_scorer.permute_mem(ctc_memory, beam_idx_dev, last_tokens.view(B, beam_size) + slot_offset)
+
+    # ---- hypotheses cut by the length limit (:529-541) ----
+    final_scores = beam_scores.cpu().numpy()
+    for b in range(B):
+        if done[b]:
+            continue
+        for slot in range(beam_size):
+            row = b * beam_size + slot
+            generated_hyps[b].add(torch.from_numpy(text[row, 1:].copy()), float(final_scores[row]))
+
+    # ---- best hypothesis of every sentence, padded (:543-580) ----
+    best = [sorted(h.beams, key=lambda x: x[0])[-1] for h in generated_hyps]
+    hypo_text_len = torch.tensor([len(h) for _, h in best], dtype=torch.long, device=dev)
+    if int(hypo_text_len.min()) != int(hypo_text_len.max()):
+        sent_max_len = min(int(hypo_text_len.max()), hypo_maxlen)
+        hypo_text = torch.full((B, sent_max_len), padding_idx, dtype=torch.long, device=dev)
+        for i, (_, h) in enumerate(best):
+            hypo_text[i, :len(h)] = h.to(dev)
+    else:
+        hypo_text = torch.stack([h for _, h in best]).to(dev)
+    return dict(hypo_text=hypo_text, hypo_text_len=hypo_text_len, feat_token_len_ratio=enc_feat_len / (hypo_text_len + 1e-10),
+                hypo_text_confid=torch.Tensor([s for s, _ in best]))

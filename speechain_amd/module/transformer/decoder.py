@@ -53,6 +53,51 @@ class TransformerDecoderLayer(Module):
         return out, self_attmat, encdec_attmat
 
 
+    # ---- cached decoding (inference) ----
+    def cross_kv(self, src: torch.Tensor) -> torch.Tensor:
+        """(B, Tk, 2 d) keys | values of the encoder-decoder attention, computed once per utterance."""
+        a = self.encdec_att
+        return Fn.linear(Fn.to_compute(src), [a.k_layer.weight, a.v_layer.weight], [a.k_layer.bias, a.v_layer.bias])
+
+    def forward_step(self, x: torch.Tensor, self_cache: torch.Tensor, table: torch.Tensor, pos: int, cross_kv: torch.Tensor,
+                     src_mask: torch.Tensor, beam: int) -> torch.Tensor:
+        """One position per hypothesis row: x (N, d) -> (N, d).  Same arithmetic as :meth:`forward` on the last position of a prefix,
+        with the earlier positions' keys / values taken from ``self_cache`` (N, Tmax, 2 d) through the ancestry ``table`` and the
+        encoder side from ``cross_kv`` (B, Tk, 2 d), shared by the ``beam`` adjacent rows of a sentence."""
+        first = self.layernorm_first
+        sa, ea = self.self_att, self.encdec_att
+        d, H = sa.d_model, sa.num_heads
+        xn = _ln(self.self_att_ln, x) if first else x
+        qkv = Fn.linear(xn, [sa.q_layer.weight, sa.k_layer.weight, sa.v_layer.weight], [sa.q_layer.bias, sa.k_layer.bias, sa.v_layer.bias])
+        ctx = Fn.attention_decode(qkv, self_cache, table, pos, H, sa.scale)
+        x = Fn.linear(ctx, [sa.output_layer.weight], [sa.output_layer.bias], residual=x)
+        if not first:
+            x = _ln(self.self_att_ln, x)
+        xn = _ln(self.encdec_att_ln, x) if first else x
+        q = Fn.linear(xn, [ea.q_layer.weight], [ea.q_layer.bias])
+        B = cross_kv.size(0)
+        ctx, _ = Fn.attention_core(q.view(B, beam, d), cross_kv, 0, 0, 1, H, d, src_mask, False, ea.scale, 0.0)
+        x = Fn.linear(ctx.reshape(B * beam, d), [ea.output_layer.weight], [ea.output_layer.bias], residual=x)
+        if not first:
+            x = _ln(self.encdec_att_ln, x)
+        xn = _ln(self.fdfwd_ln, x) if first else x
+        x = self.feed_forward(xn, _residual=x, _res_drop=0.0)
+        if not first:
+            x = _ln(self.fdfwd_ln, x)
+        return x
+
+
+class DecodeCache:
+    """State of a cached decoding run over N = sentences * beam hypothesis rows (see csrc/decode.hip): per layer the self-attention
+    key | value slots (N, Tmax, 2 d) and the encoder-side keys | values (B, Tk, 2 d); the two ancestry tables; the next position."""
+
+    def __init__(self, self_kv, cross_kv, src_mask, beam: int, max_len: int, device):
+        self.self_kv, self.cross_kv, self.src_mask, self.beam, self.max_len = self_kv, cross_kv, src_mask, beam, max_len
+        N = self_kv[0].size(0)
+        self.tables = [torch.zeros(N, max_len, dtype=torch.int32, device=device) for _ in range(2)]
+        self.pos = 0
+
+
 class TransformerDecoder(Module):
     def module_init(self, posenc_type: str = "mix", posenc_maxlen: int = 5000, posenc_dropout: float = 0.1,
                     posenc_scale: bool = False, posenc_init_alpha: float = 1.0, emb_layernorm: bool = False,
@@ -91,3 +136,33 @@ class TransformerDecoder(Module):
         if self.layernorm_first:
             tgt = _ln(self.layernorm, tgt)
         return tgt, self_attmat, encdec_attmat, hidden
+
+    # ---- cached decoding (inference): the reference re-runs forward() on the whole prefix at every step of its
+    # beam search (speechain/infer_func/beam_search.py:325-333) ----
+    def init_cache(self, src: torch.Tensor, src_mask: torch.Tensor, beam: int, max_len: int) -> DecodeCache:
+        """src (B, Tk, d) encoder output of the B sentences (NOT repeated per beam), src_mask (B, 1, Tk)."""
+        src = Fn.to_compute(src)
+        B = src.size(0)
+        N, d = B * beam, self.d_model
+        with torch.no_grad():
+            cross = [layer.cross_kv(src) for layer in self.trfm_layers]
+        self_kv = [torch.zeros(N, max_len, 2 * d, dtype=src.dtype, device=src.device) for _ in self.trfm_layers]
+        return DecodeCache(self_kv, cross, src_mask, beam, max_len, src.device)
+
+    def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None) -> torch.Tensor:
+        """tgt (N, d): the embedded token every hypothesis row feeds at position ``cache.pos``; ``beam_idx`` (N,) int64: the row each
+        hypothesis continues (the selection of the previous step; None = unchanged order).  Returns the (N, d) decoder output of that
+        position -- what ``forward`` gives at the last position of the prefix."""
+        pos = cache.pos
+        if pos >= cache.max_len:
+            raise RuntimeError(f"speechain_amd: the decoding cache holds {cache.max_len} positions")
+        with torch.no_grad():
+            t_in, t_out = cache.tables[pos & 1 ^ 1], cache.tables[pos & 1]
+            Fn.beam_table_update(t_in if pos > 0 else None, t_out, beam_idx, pos)
+            x = self.posenc.forward_step(tgt, pos)
+            for layer, kv, ckv in zip(self.trfm_layers, cache.self_kv, cache.cross_kv):
+                x = layer.forward_step(x, kv, t_out, pos, ckv, cache.src_mask, cache.beam)
+            if self.layernorm_first:
+                x = _ln(self.layernorm, x)
+        cache.pos = pos + 1
+        return x

@@ -60,6 +60,17 @@ class PositionalEncoding(Module):
         return Fn.posenc_add(x, self.posenc, self.alpha if hasattr(self, "alpha") else None,
                              math.sqrt(self.d_model) if self.emb_scale else 1.0, p)
 
+    def forward_step(self, emb: torch.Tensor, pos: int):
+        """:meth:`forward` (evaluation mode) for the single position ``pos`` of every row: emb (N, d) -> (N, d)."""
+        if pos >= self.posenc.size(1):
+            self.update_posenc(pos + 1)
+        x = Fn.to_compute(emb).unsqueeze(1)
+        if hasattr(self, "emb_layernorm"):
+            ln = self.emb_layernorm
+            x = Fn.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        return Fn.posenc_add(x, self.posenc[:, pos:pos + 1], self.alpha if hasattr(self, "alpha") else None,
+                             math.sqrt(self.d_model) if self.emb_scale else 1.0, 0.0).squeeze(1)
+
     def get_recordable_para(self) -> Dict or None:
         return dict(alpha=self.alpha) if hasattr(self, "alpha") else None
 

@@ -635,7 +635,7 @@ def g10_tts():
 
 # ---- G11 inference callers: beam search, CTC prefix scorer, prefix decoding ------------------------------------
 
-DECODE_SMALL = dict(d_model=32, num_heads=2, dec_layers=2, fdfwd_dim=64, vocab_size=23, activation="GELU")
+DECODE_SMALL = dict(d_model=128, num_heads=2, dec_layers=2, fdfwd_dim=128, vocab_size=23, activation="GELU")  # heads of 64: the cached kernels' size
 
 
 def g11_decode():
@@ -660,8 +660,8 @@ def g11_decode():
                                               fdfwd_activation=c["activation"], posenc_dropout=0.0, att_dropout=0.0, fdfwd_dropout=0.0,
                                               res_dropout=0.0, emb_scale=False, posenc_maxlen=100)))
     ctc_layer = TokenPostnet(input_size=d, vocab_size=V)
-    sd = seeded_state(dec, 111, scale=0.35)
-    sd_ctc = seeded_state(ctc_layer, 112, scale=0.5)
+    sd = seeded_state(dec, 111, scale=0.18)
+    sd_ctc = seeded_state(ctc_layer, 112, scale=0.25)
     with torch.no_grad():
         dec.postnet.linear.bias[V - 1] += 1.5  # <sos/eos> likely enough for some hypotheses to end before the length limit
     sd = {k: v.clone() for k, v in dec.state_dict().items()}

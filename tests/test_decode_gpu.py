@@ -1,0 +1,134 @@
+"""GPU: the inference callers of SURVEY.md row f3 through the HIP path -- cached-key/value decoding (sc_attention_decode,
+sc_beam_table_update behind TransformerDecoder.forward_step / ARASRDecoder), CTC prefix scores (sc_ctc_prefix_scores / _state behind
+CTCPrefixScorer) and beam_searching -- against the golden vectors of the imported reference (tests/golden/g11_decode.npz) and the oracle."""
+import math
+
+import pytest
+import torch
+
+from conftest import sub
+
+pytestmark = pytest.mark.gpu
+
+V = 23
+DEC_CONF = dict(vocab_size=V, embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=128)),
+                decoder=dict(type="transformer.decoder.TransformerDecoder",
+                             conf=dict(num_heads=2, num_layers=2, fdfwd_dim=128, fdfwd_activation="GELU", posenc_dropout=0.0,
+                                       att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0, emb_scale=False, posenc_maxlen=100)))
+CASES = dict(a=dict(beam_size=4, min_f2t_ratio=1.5),
+             b=dict(beam_size=4, min_f2t_ratio=-8, ctc_weight=0.3, temperature=1.3, length_penalty=1.2, ctc_temperature=1.1),
+             c=dict(beam_size=3, min_f2t_ratio=2.0, eos_filtering=True, eos_threshold=1.2),
+             d=dict(beam_size=2, min_f2t_ratio=-9, ctc_weight=0.5))
+
+
+def build(g):
+    from speechain_amd.module.decoder.ar_asr import ARASRDecoder
+    from speechain_amd.module.postnet.token import TokenPostnet
+
+    dec = ARASRDecoder(**DEC_CONF).cuda().eval()
+    missing, unexpected = dec.load_state_dict({k: v.float() for k, v in sub(g, "sd.decoder.").items()}, strict=False)
+    assert not unexpected and all(m.endswith("posenc.posenc") for m in missing), (missing, unexpected)
+    ctc = TokenPostnet(input_size=128, vocab_size=V).cuda().eval()
+    ctc.load_state_dict({k: v.float() for k, v in sub(g, "sd.ctc_layer.").items()})
+    return dec, ctc
+
+
+def test_attention_decode_against_dense_attention():
+    """sc_attention_decode + sc_beam_table_update over 70 steps with random beam re-orderings: the context of every row equals dense
+    softmax attention over that row's own history (gathered on the host side of the test), f32 and bf16."""
+    from speechain_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(3)
+    N, H, d, Tmax = 12, 2, 128, 80
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        cache = torch.zeros(N, Tmax, 2 * d, dtype=dtype, device="cuda")
+        tables = [torch.zeros(N, Tmax, dtype=torch.int32, device="cuda") for _ in range(2)]
+        hist_k = torch.zeros(N, 0, d)
+        hist_v = torch.zeros(N, 0, d)
+        beam_idx = None
+        for pos in range(70):
+            qkv = torch.randn(N, 3 * d, generator=gen).to(dtype)
+            t_out = tables[pos & 1]
+            Fn.beam_table_update(tables[pos & 1 ^ 1] if pos else None, t_out, beam_idx, pos)
+            out = Fn.attention_decode(qkv.cuda(), cache, t_out, pos, H, 1.0 / math.sqrt(d))
+            if beam_idx is not None:
+                hist_k, hist_v = hist_k[beam_idx.cpu()], hist_v[beam_idx.cpu()]
+            q, k, v = qkv.float().split(d, dim=1)
+            hist_k, hist_v = torch.cat([hist_k, k[:, None]], 1), torch.cat([hist_v, v[:, None]], 1)
+            qh = q.view(N, H, 1, 64)
+            kh, vh = hist_k.view(N, -1, H, 64).transpose(1, 2), hist_v.view(N, -1, H, 64).transpose(1, 2)
+            want = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), -1) @ vh).reshape(N, d)
+            assert float((out.float().cpu() - want).abs().max()) < tol, (dtype, pos, float((out.float().cpu() - want).abs().max()))
+            beam_idx = torch.randint(0, N, (N,), generator=gen).cuda() if pos % 3 else None  # (every third step keeps the order)
+
+
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16], ids=["f32", "bf16"])
+def test_cached_decoder_step_equals_prefix_decoding(golden, dtype):
+    """ARASRDecoder.forward_step fed token by token (two beams per sentence, same tokens) gives, at every position, the logits
+    ``forward`` gives on the prefix -- and, in f32, those of the imported reference (g11 pref_logits)."""
+    from speechain_amd import functional as Fn
+    from speechain_amd.utilbox.train_util import make_mask_from_len
+
+    g = golden("g11_decode")
+    dec, _ = build(g)
+    Fn.set_compute_dtype(dtype)
+    try:
+        enc, enc_len = g["enc"].cuda(), g["enc_len"].cuda()
+        mask = make_mask_from_len(enc_len, max_len=enc.size(1)).cuda()
+        text, text_len = g["pref_text"].cuda(), g["pref_text_len"]
+        with torch.no_grad():
+            full = dec(enc, mask, text, text_len.cuda())[0].float()
+        tol = 1e-4 if dtype is None else 0.03 * float(full.abs().max()) + 0.03  # bf16: two roundings of values of that size
+        if dtype is None:
+            assert float((full.cpu() - g["pref_logits"]).abs().max()) < tol
+        beam = 2
+        cache = dec.start_decoding(enc, mask, beam, 10)
+        for pos in range(text.size(1)):
+            step = dec.forward_step(text[:, pos].repeat_interleave(beam), cache).float()
+            for b in range(text.size(0)):
+                if pos < int(text_len[b]):  # (beyond a prefix's end forward() sees padding-masked positions; a step does not)
+                    for s in range(beam):
+                        err = float((step[b * beam + s] - full[b, pos]).abs().max())
+                        assert err < tol, (pos, b, s, err)
+    finally:
+        Fn.set_compute_dtype(None)
+
+
+def test_ctc_prefix_scorer_against_reference_trace(golden):
+    from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
+
+    g = golden("g11_decode")
+    sc = CTCPrefixScorer(x=g["ctc_x"].cuda(), enc_lens=g["ctc_lens"].cuda(), batch_size=2, beam_size=3, blank_index=0, eos_index=8)
+    text, state = torch.zeros(6, 0, dtype=torch.long, device="cuda"), None
+    for step in range(3):
+        psi, state = sc.forward_step(text, state)
+        want = g[f"ctc_psi{step}"]
+        assert torch.allclose(psi.cpu(), want, atol=2e-4, rtol=1e-5), (step, float((psi.cpu() - want).abs().max()))
+        beam_idx, tokens = g[f"ctc_beam_idx{step}"].cuda(), g[f"ctc_tokens{step}"].cuda()
+        text = torch.cat([text[beam_idx], tokens[:, None]], dim=1)
+        state = sc.permute_mem(state, beam_idx, tokens.view(2, 3) + (torch.arange(3, device="cuda") * 9)[None, :])
+        assert torch.allclose(state[0].cpu(), g[f"ctc_r{step}"], atol=2e-4, rtol=1e-5), step
+        assert torch.allclose(state[1][:, 0].cpu(), g[f"ctc_psimem{step}"], atol=2e-4, rtol=1e-5), step
+    psi, _ = sc.forward_step(text, state)
+    assert torch.allclose(psi.cpu(), g["ctc_psi3"], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cached", [True, False], ids=["cached", "prefix"])
+def test_beam_search_against_reference(golden, cached):
+    """beam_searching on the HIP path (f32) returns the reference's hypotheses, lengths and confidences for the four argument sets of
+    g11 -- with the cached decoder and with the decoder wrapped as a plain function (the reference's calling convention)."""
+    from speechain_amd.infer_func.beam_search import beam_searching
+    from speechain_amd.utilbox.train_util import make_mask_from_len
+
+    g = golden("g11_decode")
+    dec, ctc = build(g)
+    enc, enc_len = g["enc"].cuda(), g["enc_len"].cuda()
+    mask = make_mask_from_len(enc_len, max_len=enc.size(1)).cuda()
+    fn = dec if cached else (lambda enc_feat, enc_feat_mask, text, text_len: dec(enc_feat, enc_feat_mask, text, text_len))
+    for name, kw in CASES.items():
+        res = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=fn, ctc_decode_fn=ctc, vocab_size=V, sos_eos=V - 1,
+                             padding_idx=0, **kw)
+        assert torch.equal(res["hypo_text"].cpu(), g[f"{name}.hypo_text"]), (name, res["hypo_text"], g[f"{name}.hypo_text"])
+        assert torch.equal(res["hypo_text_len"].cpu(), g[f"{name}.hypo_text_len"]), name
+        assert torch.allclose(res["hypo_text_confid"], g[f"{name}.hypo_text_confid"].float(), atol=2e-4), name
+        assert torch.allclose(res["feat_token_len_ratio"].cpu(), g[f"{name}.feat_token_len_ratio"].float(), atol=1e-5), name

@@ -6,7 +6,7 @@ from conftest import sub
 from oracle import cpu_ref as R
 from oracle import decode_ref as D
 
-CFG = dict(d_model=32, num_heads=2, dec_layers=2, activation="GELU", emb_scale=False)
+CFG = dict(d_model=128, num_heads=2, dec_layers=2, activation="GELU", emb_scale=False)
 V = 23
 CASES = dict(a=dict(beam_size=4, min_f2t_ratio=1.5),
              b=dict(beam_size=4, min_f2t_ratio=-8, ctc_weight=0.3, temperature=1.3, length_penalty=1.2, ctc_temperature=1.1),
