@@ -36,9 +36,10 @@ def parse():
     #  measured inside the timed region -- and takes ~26 ms instead of ~12.7; over 20 steps that alone adds 0.65 ms to the average)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend", "tts_train_step"],
+    ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend", "tts_train_step", "asr_decode"],
                     help="asr_train_step = the headline metric (BASELINE configs[2]); frontend = configs[1]; tts_train_step = configs[4] "
-                         "(FastSpeech2 train step, 32 x 7.4 s @ 22.05 kHz: a secondary line with its own metric name)")
+                         "(FastSpeech2 train step, 32 x 7.4 s @ 22.05 kHz: a secondary line with its own metric name); asr_decode = SURVEY "
+                         "row f3 (encoder + beam search, beam 16, CTC weight 0.2: a secondary line with its own metric name)")
     ap.add_argument("--prenet-dims", default="64,64",
                     help="conv channels of the Conv2d prenet in front of the encoder (SURVEY row f2; HIP path, FLOPs outside the named-path count). "
                          "64,64 = the transformer-wide recipes (and the module default); 512,512 = the transformer-large recipes (conv_dims = d_model)")
@@ -598,6 +599,106 @@ def cpu_baseline_tts(seconds: float):
                 sample=f"{n} FastSpeech2 steps (fwd+bwd, no optimizer) over {nb} of the 32 utterances each, torch-CPU oracle, fp32, {cores} threads, {dt:.1f} s")
 
 
+DECODE_CONF = dict(beam_size=16, ctc_weight=0.2)  # infer_cfg of the transformer recipes (100-bpe5k_transformer-large_lr2e-3.yaml:89-94)
+
+
+class ASRDecodeWorkload:
+    """the reference's ARASR.inference step 1 (model/ar_asr.py:854-878) on one batch -- 12-layer encoder over the
+    (32, 249, 512) prenet output, then beam search over the 6-layer decoder with joint CTC scoring, beam 16, CTC weight 0.2, length
+    limit 249 / 3 = 83 tokens.  Random weights never emit <sos/eos> early, so every sentence runs to the limit: 82 decoder steps of 512
+    hypothesis rows.  Cached keys / values, CTC prefix scores and the ancestry tables are HIP kernels; the beam bookkeeping is host code
+    fed by one device-to-host copy per step."""
+
+    dtype = "bf16"
+    name = ("ASR beam-search decoding (12enc/6dec d512 h8 ffn2048, bpe5k, bf16): encoder + beam search, beam 16, joint CTC prefix "
+            "scoring weight 0.2, 82 cached-KV decoder steps of 512 hypothesis rows per 32-utterance batch (SURVEY f3)")
+
+    def __init__(self, device, seed):
+        from speechain_amd import functional as Fn
+        from speechain_amd.harness import ASRTransformer
+
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.set_attention_probs(False)
+        torch.manual_seed(0)
+        self.model = ASRTransformer(**ASR_MODEL).to(device).eval()
+        g = torch.Generator().manual_seed(77 + seed)
+        self.feat = torch.randn(BATCH, 249, 512, generator=g).to(device)
+        self.feat_len = torch.full((BATCH,), 249, dtype=torch.int64, device=device)
+        self.last = None
+
+    def step(self, timed: bool, instrument: bool = False):
+        from speechain_amd._lib import lib
+
+        if instrument:
+            names = ("sc_ctc_prefix_scores", "sc_ctc_prefix_state", "sc_attention_decode", "sc_attention_fwd", "sc_gemm", "sc_layernorm_fwd")
+            lib.timing = {k: [] for k in names}
+        self.last = self.model.inference(dict(DECODE_CONF), self.feat, self.feat_len)
+        if instrument:
+            torch.cuda.synchronize()
+            self.kernel_ms = {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in lib.timing.items()}
+            lib.timing = None
+        return self.last
+
+    def roofline(self):
+        """The CTC prefix-score kernel: per launch it reads the (B, T, V) f32 log-probabilities once per beam row group (L2 serves the
+        15 other beams of a sentence) and writes psi (N, V); exp-bound rather than byte-bound at these sizes -- both figures are given."""
+        n, ms = self.kernel_ms["sc_ctc_prefix_scores"]
+        per = ms / max(n, 1)
+        T, V, N = 249, ASR_MODEL["vocab_size"], BATCH * DECODE_CONF["beam_size"]
+        alg = BATCH * T * V * 4 + N * V * 4 + T * 2 * N * 4
+        achieved = alg / (per * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "ctc_psi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
+                "note": f"{N * V * (T - 1) / (per * 1e-3) / 1e12:.2f} T exp/s: one v_exp per (row, token, frame); launches per batch "
+                        + ", ".join(f"{k} {c} x {t / max(c, 1) * 1e3:.1f} us" for k, (c, t) in self.kernel_ms.items())}
+
+
+def cpu_baseline_decode(seconds: float):
+    """The oracle's beam search (decoder re-run on the whole prefix at every step, (T, 2, N, V) CTC tensor: the reference's algorithm) on
+    the host cores for ONE of the 32 utterances, encoder included, cut after as many decoding steps as fit ~`seconds`."""
+    from oracle import cpu_ref as R
+    from oracle import decode_ref as D
+    from speechain_amd.harness import ASRTransformer
+
+    cores = min(os.cpu_count() or 1, int(os.environ.get("BENCH_CPU_THREADS", 16)))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = ASRTransformer(**ASR_MODEL)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    P["embed.weight"] = P.pop("embed.embed.weight")
+    cfg = dict(enc_layers=12, dec_layers=6, num_heads=8, d_model=512, activation="GELU", emb_scale=False)
+    g = torch.Generator().manual_seed(77)
+    feat = torch.randn(1, 249, 512, generator=g)
+    mask = R.make_mask_from_len(torch.tensor([249]))
+    steps = {"n": 0, "t0": 0.0}
+
+    class Cut(Exception):
+        pass
+
+    def decode_fn(e, m, t, tl):
+        if steps["n"] >= 3 and time.perf_counter() - steps["t0"] > seconds:
+            raise Cut()
+        steps["n"] += 1
+        return D.asr_decode_logits(e, m, t, tl, P, cfg)
+
+    with torch.no_grad():
+        t_all = time.perf_counter()
+        enc, mask, _, _ = R.transformer_encoder(feat, mask, P, "encoder.", num_layers=12, num_heads=8, d_model=512, activation="GELU")
+        steps["t0"] = time.perf_counter()
+        try:
+            D.beam_search(enc, mask, decode_fn, 5000, sos_eos=4999, padding_idx=0, ctc_logits_fn=lambda e: R.token_postnet(e, P, "ctc_layer."),
+                          **DECODE_CONF)
+        except Cut:
+            pass
+        dt = time.perf_counter() - t_all
+    # a full utterance takes 82 steps whose cost grows with the prefix; the measured steps are the cheapest ones, so this is an upper bound
+    est = (steps["t0"] - t_all) + (time.perf_counter() - steps["t0"]) * 82 / max(steps["n"], 1)
+    return dict(value=round(1.0 / est, 5), unit="utterances/s", cores=cores, kind="port",
+                sample=f"encoder + the first {steps['n']} of 82 beam-search steps of 1 of the 32 utterances (beam 16, CTC 0.2; torch-CPU "
+                       f"oracle, fp32, {cores} threads, {dt:.1f} s), scaled to 82 steps at the measured per-step cost (an upper bound on the "
+                       f"rate: later steps decode longer prefixes)")
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
     for name in ("r02_frontend_pmc_traffic.json", "r02_train_step_pmc_traffic.json", "r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
@@ -717,6 +818,8 @@ def main():
     prenet_dims = tuple(int(c) for c in args.prenet_dims.split(","))
     if args.workload == "frontend":
         wl = FrontendWorkload(device, seed=rank)
+    elif args.workload == "asr_decode":
+        wl = ASRDecodeWorkload(device, rank)
     elif args.workload == "tts_train_step":
         TTSTrainStepWorkload.roofline = ASRTrainStepWorkload.roofline
         wl = TTSTrainStepWorkload(device, rank, world, distributed=dist is not None)
@@ -737,7 +840,7 @@ def main():
         wl.step(True)  # every timed step is the same replayed step
     fence()
     elapsed = time.perf_counter() - t0
-    if args.workload in ("asr_train_step", "tts_train_step"):
+    if args.workload in ("asr_train_step", "tts_train_step", "asr_decode"):
         # one more step, eager, with HIP events around every GEMM launch: the roofline's per-kernel times.  It runs right AFTER the timed
         # region (it takes about twice a replayed step and, on several ranks, uses the hook-launched all-reduce path), in the same
         # process, on the same weights and inputs; every rank runs it (its collectives need all of them), rank 0 reports its events.
@@ -761,6 +864,7 @@ def main():
             roof = wl.roofline()
         line = {
             "metric": ("utterances/sec (7.4 s@22.05 kHz, bsz32) FastSpeech2 train step" if args.workload == "tts_train_step" else
+                       "utterances/sec (10 s@16 kHz, bsz32) beam-search decoding, beam 16, CTC weight 0.2" if args.workload == "asr_decode" else
                        "utterances/sec (10 s@16 kHz, bsz32)"),
             "value": round(BATCH * args.steps * world / elapsed, 2),
             "unit": "utterances/s",
@@ -774,7 +878,7 @@ def main():
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": TTS_SAMPLES if args.workload == "tts_train_step" else SAMPLES,
-                       "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload == "frontend" else
+                       "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload in ("frontend", "asr_decode") else
                                     f"dp{world}: per-GPU batch 32; eager launches; the gradient all-reduce in 32 MB flat buckets is issued from "
                                     "the per-parameter hooks on a communication stream (a single rank: none)" if args.workload == "tts_train_step" else
                                     f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
@@ -797,6 +901,7 @@ def main():
                                                "heads; prenet excluded) per 32-utterance step / measured step time / dense bf16 peak"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = (cpu_baseline(args.cpu_seconds) if args.workload == "frontend" else
+                                    cpu_baseline_decode(args.cpu_seconds) if args.workload == "asr_decode" else
                                     cpu_baseline_tts(args.cpu_seconds) if args.workload == "tts_train_step" else
                                     cpu_baseline_train(args.cpu_seconds, prenet_dims))
         sys.stdout.flush()

@@ -295,7 +295,8 @@ int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache
  * int32; frames past an utterance count as certain blank (:49-57); "impossible" is the reference's finite -1e20.
  *   sc_ctc_prefix_scores: psi (N = B * beam, V) for every candidate token of every row from the forward variables r_prev (T, 2, N) of
  *     the rows' prefixes; last (N): last label of each prefix (unused when plen == 0); eos_frame (N) int32: frame whose
- *     logaddexp(r_prev[.][0], r_prev[.][1]) is the row's <eos> score (:151-155); psi(., blank) = -1e20 (:158).  T <= 4096.
+ *     logaddexp(r_prev[.][0], r_prev[.][1]) is the row's <eos> score (:151-155); psi(., blank) = -1e20 (:158).  T <= 8192 (the rows' phi / r_sum live in LDS:
+ *     2 T floats per row, up to 8 rows of a sentence per workgroup).
  *   sc_ctc_prefix_state: r_new (T, 2, N), the forward variables of the surviving candidates -- new row n = prefix of row beam_idx[n]
  *     extended by tokens[n] -- recomputed for those N pairs (the reference gathers them out of a (T, 2, N, V) tensor, :162-196). */
 int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev, const long long* last, float* psi,

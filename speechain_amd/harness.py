@@ -64,6 +64,46 @@ class ASRTransformer(torch.nn.Module):
         return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=loss, enc_hidden=enc_hidden)
 
 
+    # ---- inference: ARASR.inference step 1 (model/ar_asr.py:854-878) ----
+    def decode_step_fn(self):
+        """The decoder as ``beam_searching`` wants it: the stateless call of the reference plus cached ``start_decoding`` / ``forward_step``."""
+        return _HarnessDecoder(self)
+
+    @torch.no_grad()
+    def inference(self, infer_conf: dict, feat: torch.Tensor, feat_len: torch.Tensor):
+        """Encoder -> beam search (ctc_layer as the CTC head) -> ``hypo_text``, ``hypo_text_len``, ``feat_token_len_ratio``,
+        ``hypo_text_confid``.  feat (B, T', d_model) is the encoder input, as in :meth:`forward`."""
+        from speechain_amd.infer_func.beam_search import beam_searching
+
+        enc_mask = make_mask_from_len(feat_len, max_len=feat.size(1))
+        enc, enc_mask, _, _ = self.encoder(feat, enc_mask)
+        V = self.postnet.linear.out_features
+        return beam_searching(enc_feat=enc, enc_feat_mask=enc_mask, asr_decode_fn=self.decode_step_fn(), ctc_decode_fn=self.ctc_layer,
+                              vocab_size=V, sos_eos=V - 1, padding_idx=0, **infer_conf)
+
+
+class _HarnessDecoder:
+    """embedding -> decoder -> postnet of an :class:`ASRTransformer`, with the calling conventions of ``ARASRDecoder``."""
+
+    def __init__(self, model: ASRTransformer):
+        self.m = model
+
+    def __call__(self, enc_feat, enc_feat_mask, text, text_len):
+        m = self.m
+        tgt_mask = make_mask_from_len(text_len, max_len=text.size(1))
+        dec, sa, ea, hid = m.decoder(tgt=m.embed(text), src=enc_feat, tgt_mask=tgt_mask, src_mask=enc_feat_mask)
+        return m.postnet(dec), sa, ea, hid
+
+    def start_decoding(self, enc_feat, enc_feat_mask, beam_size: int, max_len: int):
+        return self.m.decoder.init_cache(enc_feat, enc_feat_mask, beam_size, max_len)
+
+    def forward_step(self, tokens, cache, beam_idx=None):
+        m = self.m
+        with torch.no_grad():
+            emb = m.embed(tokens.unsqueeze(1)).squeeze(1)
+            return m.postnet(m.decoder.forward_step(emb, cache, beam_idx))
+
+
 class TTSFastSpeech2(torch.nn.Module):
     """FastSpeech2 training step as SpeeChain's ``FastSpeech2`` model wires it (model/nar_tts.py:240-470 module_forward, :472-560
     criterion_forward): TTSEncoder -> FastSpeech2Decoder -> feat L1 (before + after the postnet) + pitch / energy / log-duration L2.

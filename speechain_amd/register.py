@@ -34,6 +34,10 @@ OVERLAY = {
     "speechain.module.prenet.embed": "speechain_amd.module.prenet.embed",
     "speechain.module.postnet.conv1d": "speechain_amd.module.postnet.conv1d",
     "speechain.module.encoder.tts": "speechain_amd.module.encoder.tts",
+    "speechain.module.encoder.asr": "speechain_amd.module.encoder.asr",
+    "speechain.module.decoder.ar_asr": "speechain_amd.module.decoder.ar_asr",
+    "speechain.infer_func.ctc_decoding": "speechain_amd.infer_func.ctc_decoding",
+    "speechain.infer_func.beam_search": "speechain_amd.infer_func.beam_search",
     "speechain.module.decoder.nar_tts": "speechain_amd.module.decoder.nar_tts",
     "speechain.criterion.least_error": "speechain_amd.criterion.least_error",
     "speechain.module.postnet.token": "speechain_amd.module.postnet.token",
