@@ -1573,24 +1573,24 @@ def ctc_prefix_init(x: torch.Tensor, enc_lens: torch.Tensor, beam: int, blank: i
     return r
 
 
-def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int) -> torch.Tensor:
+def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None) -> torch.Tensor:
     """psi (N, V) of every candidate token of every hypothesis row (sc_ctc_prefix_scores); r_prev None = the empty prefix."""
     require_gpu(x, "ctc_prefix_scores")
     B, T, V = x.shape
     if r_prev is None:
         r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
-    psi = torch.empty(B * beam, V, dtype=torch.float32, device=x.device)
+    psi = out if out is not None else torch.empty(B * beam, V, dtype=torch.float32, device=x.device)
     lib.call("sc_ctc_prefix_scores", _p(x), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B, beam, T, V, int(plen),
              int(blank), int(eos), stream())
     return psi
 
 
-def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int) -> torch.Tensor:
+def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int, out=None) -> torch.Tensor:
     """Forward variables (T, 2, N) of the rows that continue row beam_idx[n] with tokens[n] (sc_ctc_prefix_state)."""
     B, T, V = x.shape
     if r_prev is None:
         r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
-    r_new = torch.empty(T, 2, B * beam, dtype=torch.float32, device=x.device)
+    r_new = out if out is not None else torch.empty(T, 2, B * beam, dtype=torch.float32, device=x.device)
     lib.call("sc_ctc_prefix_state", _p(x), _p(enc_lens), _p(r_prev.contiguous()), _p(last), _p(beam_idx.contiguous()), _p(tokens), _p(r_new),
              B, beam, T, V, int(plen), int(blank), stream())
     return r_new

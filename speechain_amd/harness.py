@@ -66,8 +66,11 @@ class ASRTransformer(torch.nn.Module):
 
     # ---- inference: ARASR.inference step 1 (model/ar_asr.py:854-878) ----
     def decode_step_fn(self):
-        """The decoder as ``beam_searching`` wants it: the stateless call of the reference plus cached ``start_decoding`` / ``forward_step``."""
-        return _HarnessDecoder(self)
+        """The decoder as ``beam_searching`` wants it: the stateless call of the reference plus cached ``start_decoding`` / ``forward_step``.
+        One object per model: the replayed decoding session (buffers, hipGraphs) is kept on it between calls."""
+        if getattr(self, "_decode_fn", None) is None:
+            object.__setattr__(self, "_decode_fn", _HarnessDecoder(self))
+        return self._decode_fn
 
     @torch.no_grad()
     def inference(self, infer_conf: dict, feat: torch.Tensor, feat_len: torch.Tensor):
@@ -94,8 +97,8 @@ class _HarnessDecoder:
         dec, sa, ea, hid = m.decoder(tgt=m.embed(text), src=enc_feat, tgt_mask=tgt_mask, src_mask=enc_feat_mask)
         return m.postnet(dec), sa, ea, hid
 
-    def start_decoding(self, enc_feat, enc_feat_mask, beam_size: int, max_len: int):
-        return self.m.decoder.init_cache(enc_feat, enc_feat_mask, beam_size, max_len)
+    def start_decoding(self, enc_feat, enc_feat_mask, beam_size: int, max_len: int, reuse=None):
+        return self.m.decoder.init_cache(enc_feat, enc_feat_mask, beam_size, max_len, reuse)
 
     def forward_step(self, tokens, cache, beam_idx=None):
         m = self.m

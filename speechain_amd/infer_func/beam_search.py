@@ -10,17 +10,23 @@ What differs underneath:
   * the encoder output is not repeated per beam (:258-274): the beams of a sentence are adjacent rows and never leave it;
   * the CTC prefix scores come from ``sc_ctc_prefix_scores`` (no (T, 2, N, V) tensor, see ``infer_func/ctc_decoding.py``);
   * the step's bookkeeping reads ONE small device-to-host copy (the 2 x beam best candidates per sentence) where the reference reads a
-    scalar per candidate (``.item()``, :446-506); hypotheses live on the host as integer arrays.
+    scalar per candidate (``.item()``, :446-506); hypotheses live on the host as integer arrays;
+  * with a cached decoder the device side of a step -- ancestry table, 6 decoder layers, token head, log-softmax, CTC prefix scores,
+    score mixing, top-k -- touches only buffers that live as long as the decode function and, from the second call on, is replayed from
+    one hipGraph per position (``SC_DECODE_NO_GRAPH=1``: eager launches of the same code).
 """
+import os
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
 
+from speechain_amd import functional as Fn
 from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
 
 eps = 1e-20
 minus_inf = -1e20
+REPLAY_GRAPHS = True  # set False to launch every step eagerly (instrumented runs: per-launch timing sees nothing inside a replay)
 
 
 class BeamHypotheses:
@@ -60,6 +66,100 @@ def _first_output(out):
     return out[0] if isinstance(out, (tuple, list)) else out
 
 
+class _Session:
+    """Device side of the cached beam search for one geometry (sentences, beam, vocabulary, frames, length limit, scoring constants):
+    the buffers every step reads and writes, and one hipGraph per position.  Kept on the decode function between calls."""
+
+    def __init__(self, fn, B, beam, V, T, max_len, dev, ctc_weight, temperature, pad, sos_eos, eos_filtering):
+        self.fn, self.B, self.beam, self.V, self.T, self.max_len, self.dev = fn, B, beam, V, T, max_len, dev
+        self.ctc_weight, self.temperature, self.pad, self.sos_eos, self.eos_filtering = ctc_weight, temperature, pad, sos_eos, eos_filtering
+        N = B * beam
+        self.tokens = torch.zeros(N, dtype=torch.long, device=dev)
+        self.prev_tokens = torch.zeros(N, dtype=torch.long, device=dev)
+        self.beam_idx = torch.zeros(N, dtype=torch.long, device=dev)
+        self.scores = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.pack = torch.zeros(B, (6 if eos_filtering else 4) * beam, dtype=torch.float64, device=dev)
+        self.ctc = ctc_weight > 0
+        if self.ctc:
+            self.x = torch.empty(B, T, V, dtype=torch.float32, device=dev)
+            self.enc_lens = torch.empty(B, dtype=torch.int32, device=dev)
+            self.eos_frame = torch.empty(N, dtype=torch.int32, device=dev)
+            self.r = [torch.empty(T, 2, N, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.psi = [torch.empty(N, V, dtype=torch.float32, device=dev) for _ in range(2)]
+            self.psi_sel = torch.empty(N, dtype=torch.float32, device=dev)
+        self.cache, self.graphs, self.pool, self.calls = None, {}, None, 0
+        self.use_graphs = os.environ.get("SC_DECODE_NO_GRAPH", "0") != "1"
+
+    def begin(self, enc_feat, enc_feat_mask, scorer: Optional[CTCPrefixScorer]):
+        self.calls += 1
+        self.cache = self.fn.start_decoding(enc_feat, enc_feat_mask, self.beam, self.max_len, reuse=self.cache)
+        self.tokens.fill_(self.sos_eos)
+        self.scores.fill_(float("-inf"))
+        self.scores[::self.beam] = 0.0  # one live beam per sentence at the first step (:303-311)
+        if self.ctc:
+            self.x.copy_(scorer.x)
+            self.enc_lens.copy_(scorer.enc_lens)
+            self.eos_frame.copy_(scorer.eos_frame)
+            self.r[0].copy_(Fn.ctc_prefix_init(self.x, self.enc_lens, self.beam, self.pad))
+
+    def _device_step(self, pos: int):
+        B, beam, V, w = self.B, self.beam, self.V, self.ctc_weight
+        with torch.no_grad():
+            if self.ctc and pos > 0:  # forward variables and prefix scores of the candidates chosen at the last step
+                Fn.ctc_prefix_state(self.x, self.enc_lens, self.r[pos & 1 ^ 1], self.prev_tokens, pos - 1, self.beam_idx, self.tokens, beam,
+                                    self.pad, out=self.r[pos & 1])
+                self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
+            self.cache.pos = pos
+            logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
+            nts = torch.log_softmax(logits.float() / self.temperature, dim=-1)
+            if self.ctc:
+                nts[:, self.pad] = minus_inf  # the blank is never a token (:339)
+                psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
+                                           beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
+                nts = (1 - w) * nts + w * (psi - self.psi_sel[:, None] if pos > 0 else psi)
+            cand = (nts + self.scores[:, None]).view(B, beam * V)
+            top_scores, top_ids = torch.topk(cand, 2 * beam, dim=1, largest=True, sorted=True)
+            fetch = [top_scores.to(torch.float64), top_ids.to(torch.float64)]
+            if self.eos_filtering:
+                others = nts.clone()
+                others[:, self.sos_eos] = float("-inf")
+                fetch += [nts[:, self.sos_eos].view(B, beam).to(torch.float64), others.max(dim=-1).values.view(B, beam).to(torch.float64)]
+            self.pack.copy_(torch.cat(fetch, dim=1))
+            self.prev_tokens.copy_(self.tokens)
+
+    def step(self, pos: int) -> np.ndarray:
+        """Runs position `pos` on the rows described by tokens / beam_idx / scores; returns the packed candidates on the host."""
+        if self.use_graphs and REPLAY_GRAPHS and self.calls >= 2:  # (the first call runs eagerly: it also fills the cached bf16 weights)
+            g = self.graphs.get(pos)
+            if g is None:
+                if self.pool is None:
+                    self.pool = torch.cuda.graph_pool_handle()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                    self._device_step(pos)
+                self.graphs[pos] = g
+            g.replay()
+        else:
+            self._device_step(pos)
+        return self.pack.cpu().numpy()  # the step's one device-to-host copy
+
+
+def _session_for(fn, key, *args) -> _Session:
+    store = getattr(fn, "_sc_decode_sessions", None)
+    if store is None:
+        store = {}
+        try:
+            object.__setattr__(fn, "_sc_decode_sessions", store)
+        except Exception:
+            return _Session(fn, *args)
+    if key not in store:
+        if len(store) >= 4:  # (a session holds caches and graphs: keep the few most recent geometries)
+            store.pop(next(iter(store)))
+        store[key] = _Session(fn, *args)
+    return store[key]
+
+
 def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_decode_fn: Callable, vocab_size: int, sos_eos: int = None,
                    padding_idx: int = 0, beam_size: int = 1, min_f2t_ratio: float = 3.0, length_penalty: float = 1.0,
                    temperature: float = 1.0, eos_filtering: bool = False, eos_threshold: float = 1.5, ctc_weight: float = 0.0,
@@ -85,7 +185,6 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
     N, V = B * beam_size, vocab_size
     cached = hasattr(asr_decode_fn, "start_decoding") and hasattr(asr_decode_fn, "forward_step")
     use_lm = lm_decode_fn is not None and lm_weight > 0
-    need_prefix_on_device = (not cached) or use_lm
 
     # ---- CTC scorer: one copy of the log-probabilities per sentence ----
     ctc_scorer, ctc_memory = None, None
@@ -97,10 +196,15 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
                                      beam_size=beam_size, blank_index=padding_idx, eos_index=sos_eos)
 
     # ---- decoder state ----
-    if cached:
-        cache = asr_decode_fn.start_decoding(enc_feat, enc_feat_mask, beam_size, max(hypo_maxlen, 1))
-        enc_rep = mask_rep = None
-    if need_prefix_on_device:
+    session = None
+    if cached and not use_lm:
+        w = float(ctc_weight) if ctc_scorer is not None else 0.0
+        key = (B, beam_size, V, feat_maxlen, max(hypo_maxlen, 1), str(enc_feat.dtype), str(dev), w, float(temperature), padding_idx, sos_eos,
+               bool(eos_filtering), str(Fn.compute_dtype()))
+        session = _session_for(asr_decode_fn, key, B, beam_size, V, feat_maxlen, max(hypo_maxlen, 1), dev, w, float(temperature), padding_idx,
+                               sos_eos, bool(eos_filtering))
+        session.begin(enc_feat, enc_feat_mask, ctc_scorer)
+    if session is None:  # (with a language model in the loop the decoder is called the reference's way as well)
         enc_rep = enc_feat.repeat_interleave(beam_size, dim=0)
         mask_rep = enc_feat_mask.repeat_interleave(beam_size, dim=0)
 
@@ -110,28 +214,21 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
     beam_scores[::beam_size] = 0.0  # one live beam per sentence at the first step (:303-311)
     text = np.full((N, 1), sos_eos, dtype=np.int64)  # the hypotheses, on the host
     text_len = np.ones(N, dtype=np.int64)
-    last_tokens = torch.full((N,), sos_eos, dtype=torch.long, device=dev)
-    beam_idx_dev = None
     slot_offset = (torch.arange(beam_size, device=dev) * V)[None, :]
 
-    while int(text_len.max()) < hypo_maxlen:
-        # ---- attention decoder: log-probabilities of the next token of every row ----
+    def prefix_step():
+        """The reference's calling convention: decoder (and language model) on the whole prefix; returns the packed candidates."""
+        nonlocal ctc_memory
         with torch.no_grad():
-            if cached:
-                logits = asr_decode_fn.forward_step(last_tokens, cache, beam_idx_dev)
-            else:
-                text_dev = torch.from_numpy(text).to(dev)
-                len_dev = torch.from_numpy(text_len).to(dev)
-                logits = _first_output(asr_decode_fn(enc_feat=enc_rep, enc_feat_mask=mask_rep, text=text_dev, text_len=len_dev))[:, -1, :]
+            text_dev = torch.from_numpy(text).to(dev)
+            len_dev = torch.from_numpy(text_len).to(dev)
+            logits = _first_output(asr_decode_fn(enc_feat=enc_rep, enc_feat_mask=mask_rep, text=text_dev, text_len=len_dev))[:, -1, :]
             next_token_scores = torch.log_softmax(logits.float() / temperature, dim=-1)
             if ctc_scorer is not None:
                 next_token_scores[:, padding_idx] = minus_inf  # the blank is never a token (:339)
-                g = torch.from_numpy(text[:, 1:]).to(dev)
-                ctc_token_scores, ctc_memory = ctc_scorer.forward_step(g, ctc_memory)
+                ctc_token_scores, ctc_memory = ctc_scorer.forward_step(text_dev[:, 1:], ctc_memory)
                 next_token_scores = (1 - ctc_weight) * next_token_scores + ctc_weight * ctc_token_scores
             if use_lm:  # (:348-398) a language model is called the way the reference calls it: on the (windowed) prefix
-                text_dev = torch.from_numpy(text).to(dev)
-                len_dev = torch.from_numpy(text_len).to(dev)
                 lm_text = text_dev if lm_window_size is None else text_dev[:, -lm_window_size:]
                 lm_len = len_dev if lm_window_size is None else torch.clamp(len_dev, max=lm_window_size)
                 lm_out = _first_output(lm_decode_fn(text=lm_text, text_len=lm_len))[:, -1, :]
@@ -143,12 +240,17 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
                     next_token_scores = next_token_scores - ilm_sub_weight * torch.log_softmax(ilm.float(), dim=-1)
             cand = (next_token_scores + beam_scores[:, None]).view(B, beam_size * V)
             top_scores, top_ids = torch.topk(cand, 2 * beam_size, dim=1, largest=True, sorted=True)
-            fetch = [top_scores, top_ids.to(torch.float64)]
+            fetch = [top_scores, top_ids]
             if eos_filtering:
                 others = next_token_scores.clone()
                 others[:, sos_eos] = float("-inf")
                 fetch += [next_token_scores[:, sos_eos].view(B, beam_size), others.max(dim=-1).values.view(B, beam_size)]
-            host = torch.cat([f.to(torch.float64) for f in fetch], dim=1).cpu().numpy()  # the step's one device-to-host copy
+            return torch.cat([f.to(torch.float64) for f in fetch], dim=1).cpu().numpy()  # the step's one device-to-host copy
+
+    step_no = 0
+    while int(text_len.max()) < hypo_maxlen:
+        host = session.step(step_no) if session is not None else prefix_step()
+        step_no += 1
         h_scores = host[:, :2 * beam_size].astype(np.float32)
         h_ids = host[:, 2 * beam_size:4 * beam_size].astype(np.int64)
         if eos_filtering:
@@ -185,13 +287,18 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
             break
 
         # ---- the next step's rows ----
+        text = np.concatenate([text[new_parent], new_tokens[:, None]], axis=1)
+        text_len = (text != padding_idx).sum(-1)
+        if session is not None:
+            session.scores.copy_(torch.from_numpy(new_scores))
+            session.tokens.copy_(torch.from_numpy(new_tokens))
+            session.beam_idx.copy_(torch.from_numpy(new_parent))
+            beam_scores = session.scores
+            continue
         beam_scores = torch.from_numpy(new_scores).to(dev)
         last_tokens = torch.from_numpy(new_tokens).to(dev)
         beam_idx_dev = torch.from_numpy(new_parent).to(dev)
-        text = np.concatenate([text[new_parent], new_tokens[:, None]], axis=1)
-        text_len = (text != padding_idx).sum(-1)
-        if need_prefix_on_device:
-            enc_rep, mask_rep = enc_rep[beam_idx_dev], mask_rep[beam_idx_dev]
+        enc_rep, mask_rep = enc_rep[beam_idx_dev], mask_rep[beam_idx_dev]
         if ctc_memory is not None:
             ctc_memory = ctc_scorer.permute_mem(ctc_memory, beam_idx_dev, last_tokens.view(B, beam_size) + slot_offset)
 

@@ -32,9 +32,9 @@ class ARASRDecoder(Module):
         return self.postnet(dec_feat), self_attmat, encdec_attmat, hidden
 
     # ---- cached decoding ----
-    def start_decoding(self, enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, beam_size: int, max_len: int):
+    def start_decoding(self, enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, beam_size: int, max_len: int, reuse=None):
         """enc_feat (B, T, d), enc_feat_mask (B, 1, T) of the B sentences (one copy each, not one per beam)."""
-        return self.decoder.init_cache(enc_feat, enc_feat_mask, beam_size, max_len)
+        return self.decoder.init_cache(enc_feat, enc_feat_mask, beam_size, max_len, reuse)
 
     def forward_step(self, tokens: torch.Tensor, cache, beam_idx: torch.Tensor = None) -> torch.Tensor:
         """tokens (N,) int64: the newest token of every hypothesis row; returns the (N, vocab) logits of the next one."""

@@ -139,15 +139,24 @@ class TransformerDecoder(Module):
 
     # ---- cached decoding (inference): the reference re-runs forward() on the whole prefix at every step of its
     # beam search (speechain/infer_func/beam_search.py:325-333) ----
-    def init_cache(self, src: torch.Tensor, src_mask: torch.Tensor, beam: int, max_len: int) -> DecodeCache:
-        """src (B, Tk, d) encoder output of the B sentences (NOT repeated per beam), src_mask (B, 1, Tk)."""
+    def init_cache(self, src: torch.Tensor, src_mask: torch.Tensor, beam: int, max_len: int, reuse: DecodeCache = None) -> DecodeCache:
+        """src (B, Tk, d) encoder output of the B sentences (NOT repeated per beam), src_mask (B, 1, Tk).  ``reuse``: a cache of the same
+        geometry whose buffers are refilled in place (a decoding loop replayed from hipGraphs holds their addresses)."""
         src = Fn.to_compute(src)
         B = src.size(0)
         N, d = B * beam, self.d_model
         with torch.no_grad():
             cross = [layer.cross_kv(src) for layer in self.trfm_layers]
+        if reuse is not None and reuse.beam == beam and reuse.max_len == max_len and reuse.cross_kv[0].shape == cross[0].shape \
+                and reuse.cross_kv[0].dtype == cross[0].dtype and reuse.src_mask.shape == src_mask.shape:
+            with torch.no_grad():
+                for dst, new in zip(reuse.cross_kv, cross):
+                    dst.copy_(new)
+                reuse.src_mask.copy_(src_mask)
+            reuse.pos = 0
+            return reuse
         self_kv = [torch.zeros(N, max_len, 2 * d, dtype=src.dtype, device=src.device) for _ in self.trfm_layers]
-        return DecodeCache(self_kv, cross, src_mask, beam, max_len, src.device)
+        return DecodeCache(self_kv, cross, src_mask.clone(), beam, max_len, src.device)
 
     def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None) -> torch.Tensor:
         """tgt (N, d): the embedded token every hypothesis row feeds at position ``cache.pos``; ``beam_idx`` (N,) int64: the row each
