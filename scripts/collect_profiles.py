@@ -13,7 +13,7 @@ G, P = os.path.join(ROOT, "gpurun_out", "prof") + "/", os.path.join(ROOT, "profi
 
 TRAIN_KERNELS = ("gemm_bf16_nt_dma_kernel<2, 2, 2, 2, false>", "gemm_bf16_nt_dma_kernel<2, 4, 4, 0, false>", "gemm_bf16_nt_dma_kernel<2, 2, 1, 2, false>",
                  "gemm_bf16_nt_dma_kernel<2, 1, 1, 1, false>", "wgrad_grouped_kernel<2, 4, 4>", "gemm_bf16_kernel<true, true>", "attn_fwd_stream_kernel",
-                 "attn_bwd_kernel", "adam_step_kernel", "grad_sumsq_kernel", "cast_weights_kernel", "layernorm_bwd_vec_kernel", "layernorm_fwd_vec_kernel")
+                 "attn_bwd_kl_kernel<8, true>", "attn_bwd_kl_kernel<4, true>", "adam_step_kernel", "grad_sumsq_kernel", "cast_weights_kernel", "layernorm_bwd_vec_kernel", "layernorm_fwd_vec_kernel")
 
 
 def newest(pattern):
@@ -46,9 +46,11 @@ def main():
     for src, dst in (("bench_default.json", "train_step_bench_default"), ("bench_p512.json", "train_step_bench_prenet512"),
                      ("bench_frontend.json", "frontend_bench_default"), ("bench_tts.json", "tts_step_bench_default"),
                      ("train_bench.json", "train_step_bench_under_rocprof"), ("frontend_bench.json", "frontend_bench_under_rocprof"),
-                     ("tts_bench.json", "tts_step_bench_under_rocprof")):
+                     ("tts_bench.json", "tts_step_bench_under_rocprof"), ("bench_decode.json", "decode_bench_default"),
+                     ("decode_bench.json", "decode_bench_under_rocprof")):
         shutil.copy(G + src, f"{P}{tag}_{dst}.json")
-    for d, dst in (("train", "train_step_kernel_stats"), ("frontend", "frontend_bench_kernel_stats"), ("tts", "tts_step_kernel_stats")):
+    for d, dst in (("train", "train_step_kernel_stats"), ("frontend", "frontend_bench_kernel_stats"), ("tts", "tts_step_kernel_stats"),
+                   ("decode", "decode_kernel_stats")):
         shutil.copy(newest(G + f"{d}/*/*kernel_stats.csv"), f"{P}{tag}_{dst}.csv")
     fe, rows = traffic("frontend", ("frontend_pfa400_kernel", "specaug_kernel"),
                        "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python bench.py --workload frontend --steps 5 --warmup 2`; FETCH_SIZE doubled per "
@@ -75,10 +77,14 @@ def main():
         r = d["roofline"]
         print(f"{tag}_{name}: {d['value']} utt/s, {d['ms_per_step']} ms/step; kernel {r['kernel_ms'] * 1e3:.1f} us, {r['achieved']} GB/s ({r['frac']:.3f}), traffic {r['traffic']}"
               + (f"; cpu {d['cpu_baseline']['value']} utt/s" if "cpu_baseline" in d else ""))
-    for wl, extra in (("train_step", 1), ("tts_step", 1)):
-        b = json.load(open(f"{P}{tag}_{wl}_bench_under_rocprof.json"))
+    d = json.load(open(f"{P}{tag}_decode_bench_default.json"))
+    r = d["roofline"]
+    print(f"{tag}_decode_bench_default: {d['ms_per_step']} ms per 32-utterance batch, {d['value']} utt/s; {r['kernel']} {r['kernel_ms'] * 1e3:.1f} us, {r['achieved']} GB/s; "
+          f"{r['note']}" + (f"; cpu {d['cpu_baseline']['value']} utt/s ({d['cpu_baseline']['sample'][:80]}...)" if "cpu_baseline" in d else ""))
+    for wl, extra in (("train_step", 1), ("tts_step", 1), ("decode", 1)):
+        b = json.load(open(f"{P}{tag}_{wl}_bench_under_rocprof.json" if wl != "decode" else f"{P}{tag}_decode_bench_under_rocprof.json"))
         steps = b["steps"] + b["warmup"] + extra  # (+ the instrumented eager step after the timed region)
-        rows = list(csv.DictReader(open(f"{P}{tag}_{wl}_kernel_stats.csv")))
+        rows = list(csv.DictReader(open(f"{P}{tag}_{wl}_kernel_stats.csv")))  # (decode: a "step" is one 32-utterance batch)
         print(f"--- {wl} kernel stats per step ({steps} steps traced; total {sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / steps:.2f} ms of kernels, "
               f"{sum(int(r['Calls']) for r in rows) / steps:.0f} launches per step)")
         for r in rows[:28]:
