@@ -304,6 +304,10 @@ int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_fra
 int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
                         const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream);
 
+/* Row-wise top-K of a (R, L) f32 matrix, row stride ld: vals / idx (R, K) in descending order, ties by the lower index; K <= 64.
+ * The candidate selection of a beam-search step (speechain/infer_func/beam_search.py:419-421: torch.topk over (batch, beam * vocab)). */
+int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream);
+
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
  * lse[r] is kept for the backward pass, which writes dlogits = grow[r]/temperature * (softmax - (1-eps)*onehot - eps/V). */

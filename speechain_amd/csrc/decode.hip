@@ -379,3 +379,126 @@ SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float*
   SC_LAUNCH_CHECK("ctc_state_kernel");
   return SC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-wise top-K (K <= 64) of a (R, L) f32 matrix, sorted descending, ties by the lower index: the candidate selection of a beam-search
+// step (speechain/infer_func/beam_search.py:419-421 calls torch.topk on the (batch, beam x vocabulary) score matrix; with 80 000
+// columns that is a chain of multi-block radix kernels with host-side bookkeeping -- 5 launches, and not reliably replayable from a
+// hipGraph).  One workgroup per row: three histogram rounds over the order-preserving integer image of the floats (11 + 11 + 10 bits, LDS
+// atomics) give the K-th largest key exactly; every thread then walks its contiguous share of the row once more, takes what lies above the
+// threshold and, in index order, as many equal elements as are still missing; K threads rank the K survivors against each other.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ unsigned topk_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // larger float <=> larger key (-0 < +0; NaN sorts above +inf)
+}
+
+// finds, scanning bins from the top, the bin in which the running count reaches `need`; returns it and the count above it
+__device__ __forceinline__ void topk_find_bin(const unsigned* hist, int nbins, unsigned need, int* sh_bin, unsigned* sh_above) {
+  // one wave: lane l owns bins [nbins - (l + 1) per, nbins - l per) from the top
+  const int lane = threadIdx.x;
+  if (lane < 64) {
+    const int per = nbins / 64;
+    unsigned mine = 0;
+    for (int i = 0; i < per; ++i) mine += hist[nbins - 1 - (lane * per + i)];
+    unsigned inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    const unsigned before = inc - mine;  // count in the bins above this lane's
+    if (before < need && inc >= need) {  // the crossing is in this lane's bins
+      unsigned run = before;
+      for (int i = 0; i < per; ++i) {
+        const int b = nbins - 1 - (lane * per + i);
+        if (run + hist[b] >= need) {
+          *sh_bin = b;
+          *sh_above = run;
+          break;
+        }
+        run += hist[b];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long long ld, int L, int K, float* vals, long long* idx) {
+  __shared__ unsigned hist[2048];
+  __shared__ int sh_bin;
+  __shared__ unsigned sh_above, sh_cnt, sh_eq_base[1025];
+  __shared__ unsigned sel_key[64];
+  __shared__ int sel_idx[64];
+  const int tid = threadIdx.x;
+  const float* row = x + (long long)blockIdx.x * ld;
+  const int chunk = (L + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, L);
+  unsigned prefix = 0, need = (unsigned)K;  // key bits fixed so far (from the top), elements still wanted among those matching the prefix
+  // ---- three rounds: bits [31:21], [20:10], [9:0] ----
+  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+  unsigned mask_hi = 0;  // which top bits are fixed
+  for (int rd = 0; rd < 3; ++rd) {
+    const int nb = 1 << widths[rd];
+    for (int b = tid; b < nb; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) {
+      const unsigned k = topk_key(row[i]);
+      if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shifts[rd]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    topk_find_bin(hist, nb, need, &sh_bin, &sh_above);
+    __syncthreads();
+    prefix |= (unsigned)sh_bin << shifts[rd];
+    mask_hi |= (unsigned)(nb - 1) << shifts[rd];
+    need -= sh_above;
+    __syncthreads();
+  }
+  const unsigned thr = prefix;  // the K-th largest key; `need` (>= 1) elements equal to it are wanted, lowest indices first
+  // ---- equal elements: rank by index order (threads own contiguous index ranges) ----
+  unsigned eq = 0;
+  for (int i = i0; i < i1; ++i) eq += topk_key(row[i]) == thr;
+  sh_eq_base[tid + 1] = eq;
+  if (tid == 0) {
+    sh_eq_base[0] = 0;
+    sh_cnt = 0;
+  }
+  __syncthreads();
+  if (tid == 0)
+    for (int t = 1; t <= 1024; ++t) sh_eq_base[t] += sh_eq_base[t - 1];  // (1024 adds, once per row)
+  __syncthreads();
+  unsigned eq_rank = sh_eq_base[tid];
+  for (int i = i0; i < i1; ++i) {
+    const unsigned k = topk_key(row[i]);
+    bool take = k > thr;
+    if (k == thr) take = eq_rank++ < need;
+    if (take) {
+      const unsigned slot = atomicAdd(&sh_cnt, 1u);
+      if (slot < 64) {
+        sel_key[slot] = k;
+        sel_idx[slot] = i;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- order the K survivors: descending key, ascending index ----
+  if (tid < K) {
+    const unsigned k = sel_key[tid];
+    const int id = sel_idx[tid];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) rank += (sel_key[j] > k) || (sel_key[j] == k && sel_idx[j] < id);
+    vals[(long long)blockIdx.x * K + rank] = row[id];
+    idx[(long long)blockIdx.x * K + rank] = id;
+  }
+}
+
+}  // namespace
+
+// vals / idx (R, K): the K largest elements of every row of x (R, L; row stride ld) in descending order, ties by the lower index.
+SC_API int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream) {
+  SC_CHECK_ARG(x && vals && idx, "sc_topk_rows: null pointer");
+  SC_CHECK_ARG(R >= 1 && R <= 65535 && L >= 1 && K >= 1 && K <= 64 && K <= L && ld >= L, "sc_topk_rows: bad sizes R=%d L=%d K=%d (K <= 64, K <= L)", R, L, K);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(R), dim3(1024), 0, stream, x, ld, L, K, vals, idx);
+  SC_LAUNCH_CHECK("topk_rows_kernel");
+  return SC_OK;
+}

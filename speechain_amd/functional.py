@@ -1594,3 +1594,15 @@ def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, bea
     lib.call("sc_ctc_prefix_state", _p(x), _p(enc_lens), _p(r_prev.contiguous()), _p(last), _p(beam_idx.contiguous()), _p(tokens), _p(r_new),
              B, beam, T, V, int(plen), int(blank), stream())
     return r_new
+
+
+def topk_rows(x: torch.Tensor, k: int):
+    """(values, indices) of the k largest elements of every row of the 2-D f32 tensor x, descending, ties by the lower index
+    (sc_topk_rows; k <= 64)."""
+    require_gpu(x, "topk_rows")
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    R, L = x.shape
+    vals = torch.empty(R, k, dtype=torch.float32, device=x.device)
+    idx = torch.empty(R, k, dtype=torch.long, device=x.device)
+    lib.call("sc_topk_rows", _p(x), x.stride(0), R, L, int(k), _p(vals), _p(idx), stream())
+    return vals, idx

@@ -118,7 +118,7 @@ class _Session:
                                            beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
                 nts = (1 - w) * nts + w * (psi - self.psi_sel[:, None] if pos > 0 else psi)
             cand = (nts + self.scores[:, None]).view(B, beam * V)
-            top_scores, top_ids = torch.topk(cand, 2 * beam, dim=1, largest=True, sorted=True)
+            top_scores, top_ids = Fn.topk_rows(cand, 2 * beam) if 2 * beam <= 64 else torch.topk(cand, 2 * beam, dim=1, largest=True, sorted=True)
             fetch = [top_scores.to(torch.float64), top_ids.to(torch.float64)]
             if self.eos_filtering:
                 others = nts.clone()

@@ -133,3 +133,33 @@ def test_beam_search_against_reference(golden, cached):
         assert torch.equal(res["hypo_text_len"].cpu(), g[f"{name}.hypo_text_len"]), name
         assert torch.allclose(res["hypo_text_confid"], g[f"{name}.hypo_text_confid"].float(), atol=2e-4), name
         assert torch.allclose(res["feat_token_len_ratio"].cpu(), g[f"{name}.feat_token_len_ratio"].float(), atol=1e-5), name
+
+
+@pytest.mark.parametrize("R,L,K", [(32, 80000, 32), (3, 92, 8), (5, 5000, 64), (2, 40, 40), (4, 1025, 2)])
+def test_topk_rows_against_torch(R, L, K):
+    """sc_topk_rows: values equal torch.topk's (sorted, descending); indices point at those values; among equal values the lower index
+    comes first and wins the last place (rows with many ties, -inf runs and the reference's -1e20 included)."""
+    from speechain_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(R * 7 + L)
+    x = torch.randn(R, L, generator=gen)
+    x[0, : L // 2] = float("-inf")
+    if R > 1:
+        x[1] = torch.randint(0, 6, (L,), generator=gen).float()  # heavy ties
+    if R > 2:
+        x[2, ::3] = -1e20
+    x = x.cuda()
+    vals, idx = Fn.topk_rows(x, K)
+    want, _ = torch.topk(x, K, dim=1, largest=True, sorted=True)
+    assert torch.equal(vals, want)
+    assert torch.equal(torch.gather(x, 1, idx), vals)
+    for r in range(R):
+        v, i = vals[r].cpu(), idx[r].cpu()
+        assert len(set(i.tolist())) == K
+        for a in range(K - 1):
+            assert v[a] > v[a + 1] or (v[a] == v[a + 1] and i[a] < i[a + 1]), (r, a)
+        # the last place among equals goes to the lowest indices
+        last = v[-1]
+        eq_all = (x[r].cpu() == last).nonzero().flatten()
+        taken = i[v == last]
+        assert torch.equal(taken.sort().values, eq_all[: len(taken)])
