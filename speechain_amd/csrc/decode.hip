@@ -60,15 +60,52 @@ __global__ __launch_bounds__(256) void beam_table_kernel(const int* tin, int* to
   if (lane == 0) tout[(long long)n * Tmax + pos] = n;
 }
 
+// 16 bytes of a row as EPL floats
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int EPL = 4;
+  static __device__ __forceinline__ void ld(const float* p, float* v) {
+    const float4 a = *(const float4*)p;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Chunk<unsigned short> {
+  static constexpr int EPL = 8;
+  static __device__ __forceinline__ void ld(const unsigned short* p, float* v) {
+    const uint4 a = *(const uint4*)p;
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = __uint_as_float(w[j] << 16);
+      v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(unsigned short* p, const float* v) {
+    uint4 a;
+    a.x = sc_f32_to_bf16(v[0]) | ((unsigned)sc_f32_to_bf16(v[1]) << 16);
+    a.y = sc_f32_to_bf16(v[2]) | ((unsigned)sc_f32_to_bf16(v[3]) << 16);
+    a.z = sc_f32_to_bf16(v[4]) | ((unsigned)sc_f32_to_bf16(v[5]) << 16);
+    a.w = sc_f32_to_bf16(v[6]) | ((unsigned)sc_f32_to_bf16(v[7]) << 16);
+    *(uint4*)p = a;
+  }
+};
+
 // qkv: (N, 3 d) this step's projections [q | k | v]; cache: (N, Tmax, 2 d) [k | v]; table: (N, Tmax); out: (N, d).
-// grid (ceil(N H / 4)); one wave per (row, head); MAXP passes of 64 keys (Tmax <= 64 MAXP).
-template <typename T, int MAXP>
+// grid (ceil(N H / 4)); one wave per (row, head).  A key's 64 head dimensions are spread over LPK lanes of 16 bytes each, so that every
+// load instruction reads KPI = 64 / LPK whole rows (8 for bf16, 4 for f32); scores and probabilities pass through a per-wave LDS row.
+template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long long ldqkv, T* cache, const int* table, T* out, long long ldo,
                                                           int N, int H, int Tmax, int pos, float scale) {
-  __shared__ __attribute__((aligned(16))) float qs[4][DH];
+  constexpr int EPL = Chunk<T>::EPL, LPK = DH / EPL, KPI = 64 / LPK;
+  extern __shared__ __attribute__((aligned(16))) float dsm_dec[];  // per wave: q[64], v_new[64], s[Tmax], rows[Tmax]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + w;
   if (gw >= N * H) return;
+  float* qs = dsm_dec + (size_t)w * (2 * DH + 2 * Tmax);
+  float* vs = qs + DH;
+  float* ss = vs + DH;
+  int* rs = (int*)(ss + Tmax);
   const int n = gw / H, h = gw - n * H;
   const int d = H * DH;
   const T* row = qkv + (long long)n * ldqkv + h * DH;
@@ -77,56 +114,73 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long lon
   T* slot = cache + ((long long)n * Tmax + pos) * (2 * d) + h * DH;
   Elem<T>::st(slot + lane, kn);
   Elem<T>::st(slot + d + lane, vn);
-  qs[w][lane] = q;
+  qs[lane] = q;
+  vs[lane] = vn;
   const float s_new = sc_wave_sum(q * kn) * scale;  // the new position's own score (its key is still in registers)
-  asm volatile("" ::: "memory");  // (the wave reads its own LDS row below; LDS operations of one wave complete in order)
+  asm volatile("" ::: "memory");  // (the wave reads its own LDS rows below; LDS operations of one wave complete in order)
   const int* trow = table + (long long)n * Tmax;
-  float s[MAXP];
-  float m = s_new;
+  const int sub = lane % LPK, grp = lane / LPK;
+  float qc[EPL];
 #pragma unroll
-  for (int c = 0; c < MAXP; ++c) {
-    const int t = 64 * c + lane;
-    s[c] = -INFINITY;
-    if (64 * c < pos) {  // (wave-uniform)
-      if (t < pos) {
-        const T* kr = cache + ((long long)trow[t] * Tmax + t) * (2 * d) + h * DH;
-        s[c] = Elem<T>::dot64(kr, qs[w]) * scale;
-      }
+  for (int e = 0; e < EPL; ++e) qc[e] = qs[sub * EPL + e];
+  // ---- scores of the history ----
+  for (int k0 = 0; k0 < pos; k0 += KPI) {
+    const int key = k0 + grp;
+    float part = 0.f;
+    int r = 0;
+    if (key < pos) {
+      r = trow[key];
+      float kv[EPL];
+      Chunk<T>::ld(cache + ((long long)r * Tmax + key) * (2 * d) + h * DH + sub * EPL, kv);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) part = fmaf(kv[e], qc[e], part);
     }
-    if (t == pos) s[c] = s_new;
-    m = fmaxf(m, s[c]);
+#pragma unroll
+    for (int o = 1; o < LPK; o <<= 1) part += __shfl_xor(part, o, 64);
+    if (sub == 0 && key < pos) {
+      ss[key] = part * scale;
+      rs[key] = r;
+    }
   }
+  if (lane == 0) ss[pos] = s_new;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- softmax over positions 0 .. pos ----
+  float m = -INFINITY;
+  for (int t = lane; t <= pos; t += 64) m = fmaxf(m, ss[t]);
   m = sc_wave_max(m);
   float l = 0.f;
-#pragma unroll
-  for (int c = 0; c < MAXP; ++c) {
-    s[c] = __expf(s[c] - m);  // exp(-inf) = 0 beyond the history
-    l += s[c];
+  for (int t = lane; t <= pos; t += 64) {
+    const float e = __expf(ss[t] - m);
+    ss[t] = e;
+    l += e;
   }
   l = sc_wave_sum(l);
-  const float inv = 1.f / l;
-  // context: lane = head dimension; p_t is broadcast from the lane that scored key t
-  float acc = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- context ----
+  float acc[EPL];
 #pragma unroll
-  for (int c = 0; c < MAXP; ++c) {
-    if (64 * c < pos) {
-      const int tend = min(pos, 64 * c + 64);
-      const float pc = s[c];
-      for (int t = 64 * c; t < tend; ++t) {
-        const int r = __builtin_amdgcn_readfirstlane(trow[t]);
-        const float p = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pc), t & 63));
-        acc = fmaf(p, Elem<T>::ld(cache + ((long long)r * Tmax + t) * (2 * d) + d + h * DH + lane), acc);
-      }
+  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+  for (int k0 = 0; k0 < pos; k0 += KPI) {
+    const int key = k0 + grp;
+    if (key < pos) {
+      const float pk = ss[key];
+      float vv[EPL];
+      Chunk<T>::ld(cache + ((long long)rs[key] * Tmax + key) * (2 * d) + d + h * DH + sub * EPL, vv);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
     }
   }
-  {
-    float pn = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXP; ++c)
-      if ((pos >> 6) == c) pn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s[c]), pos & 63));
-    acc = fmaf(pn, vn, acc);
+  for (int o = LPK; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  if (grp == 0) {
+    const float pn = ss[pos], inv = 1.f / l;
+    float o8[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o8[e] = fmaf(pn, vs[sub * EPL + e], acc[e]) * inv;
+    Chunk<T>::st(out + (long long)n * ldo + h * DH + sub * EPL, o8);
   }
-  Elem<T>::st(out + (long long)n * ldo + h * DH + lane, acc * inv);
 }
 
 }  // namespace
@@ -157,23 +211,15 @@ SC_API int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void
   const long long d = (long long)H * DH;
   SC_CHECK_ARG(ldqkv >= 3 * d && ldo >= d, "sc_attention_decode: row strides too small");
   SC_CHECK_ARG(((uintptr_t)cache | (uintptr_t)qkv) % 16 == 0 && ldqkv % 8 == 0, "sc_attention_decode: buffers must be 16-byte aligned");
+  SC_CHECK_ARG(ldo % 8 == 0 && (uintptr_t)out % 16 == 0, "sc_attention_decode: the output must be 16-byte aligned with a row stride multiple of 8");
   const dim3 grid((unsigned)sc_cdiv(N * H, 4));
-  const int passes = pos / 64 + 1;
-#define SC_LAUNCH_DEC(T, P)                                                                                                          \
-  hipLaunchKernelGGL((attn_decode_kernel<T, P>), grid, dim3(256), 0, stream, (const T*)qkv, ldqkv, (T*)cache, table, (T*)out, ldo, N, H, \
-                     Tmax, pos, scale)
-  if (dtype == 0) {
-    if (passes <= 1) SC_LAUNCH_DEC(float, 1);
-    else if (passes <= 2) SC_LAUNCH_DEC(float, 2);
-    else if (passes <= 4) SC_LAUNCH_DEC(float, 4);
-    else SC_LAUNCH_DEC(float, 8);
-  } else {
-    if (passes <= 1) SC_LAUNCH_DEC(unsigned short, 1);
-    else if (passes <= 2) SC_LAUNCH_DEC(unsigned short, 2);
-    else if (passes <= 4) SC_LAUNCH_DEC(unsigned short, 4);
-    else SC_LAUNCH_DEC(unsigned short, 8);
-  }
-#undef SC_LAUNCH_DEC
+  const size_t smem = (size_t)4 * (2 * DH + 2 * Tmax) * sizeof(float);
+  if (dtype == 0)
+    hipLaunchKernelGGL(attn_decode_kernel<float>, grid, dim3(256), smem, stream, (const float*)qkv, ldqkv, (float*)cache, table, (float*)out, ldo,
+                       N, H, Tmax, pos, scale);
+  else
+    hipLaunchKernelGGL(attn_decode_kernel<unsigned short>, grid, dim3(256), smem, stream, (const unsigned short*)qkv, ldqkv,
+                       (unsigned short*)cache, table, (unsigned short*)out, ldo, N, H, Tmax, pos, scale);
   SC_LAUNCH_CHECK("attn_decode_kernel");
   return SC_OK;
 }
@@ -385,8 +431,9 @@ SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float*
 // step (speechain/infer_func/beam_search.py:419-421 calls torch.topk on the (batch, beam x vocabulary) score matrix; with 80 000
 // columns that is a chain of multi-block radix kernels with host-side bookkeeping -- 5 launches, and not reliably replayable from a
 // hipGraph).  One workgroup per row: three histogram rounds over the order-preserving integer image of the floats (11 + 11 + 10 bits, LDS
-// atomics) give the K-th largest key exactly; every thread then walks its contiguous share of the row once more, takes what lies above the
-// threshold and, in index order, as many equal elements as are still missing; K threads rank the K survivors against each other.
+// atomics, one per RUN of equal bins a lane meets: scores share an exponent and would otherwise hit one address) give the K-th largest key
+// exactly; the row is then walked once more for what lies above the threshold and the elements equal to it (lowest indices first when
+// there are more of those than places left); K threads rank the K survivors against each other.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -428,24 +475,41 @@ __device__ __forceinline__ void topk_find_bin(const unsigned* hist, int nbins, u
 __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long long ld, int L, int K, float* vals, long long* idx) {
   __shared__ unsigned hist[2048];
   __shared__ int sh_bin;
-  __shared__ unsigned sh_above, sh_cnt, sh_eq_base[1025];
+  __shared__ unsigned sh_above, sh_cnt, sh_eq_total, sh_eq_base[1025];
   __shared__ unsigned sel_key[64];
   __shared__ int sel_idx[64];
   const int tid = threadIdx.x;
   const float* row = x + (long long)blockIdx.x * ld;
-  const int chunk = (L + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, L);
   unsigned prefix = 0, need = (unsigned)K;  // key bits fixed so far (from the top), elements still wanted among those matching the prefix
-  // ---- three rounds: bits [31:21], [20:10], [9:0] ----
+  // ---- three rounds: bits [31:21], [20:10], [9:0].  Scores cluster (same exponent): a lane adds a RUN of equal bins with one atomic ----
   const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
   unsigned mask_hi = 0;  // which top bits are fixed
   for (int rd = 0; rd < 3; ++rd) {
     const int nb = 1 << widths[rd];
     for (int b = tid; b < nb; b += 1024) hist[b] = 0;
     __syncthreads();
-    for (int i = i0; i < i1; ++i) {
-      const unsigned k = topk_key(row[i]);
-      if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shifts[rd]) & (nb - 1)], 1u);
+    int cur = -1;
+    unsigned run = 0;
+    for (int i = tid; i < L; i += 8 * 1024) {  // eight loads in flight per lane (the row comes out of L2: latency, not bytes, is the cost)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i + u * 1024 < L) ? row[i + u * 1024] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned k = topk_key(v[u]);
+        if (i + u * 1024 < L && (k & mask_hi) == prefix) {
+          const int b = (int)((k >> shifts[rd]) & (unsigned)(nb - 1));
+          if (b == cur) {
+            ++run;
+          } else {
+            if (run) atomicAdd(&hist[cur], run);
+            cur = b;
+            run = 1;
+          }
+        }
+      }
     }
+    if (run) atomicAdd(&hist[cur], run);
     __syncthreads();
     topk_find_bin(hist, nb, need, &sh_bin, &sh_above);
     __syncthreads();
@@ -455,30 +519,74 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long lo
     __syncthreads();
   }
   const unsigned thr = prefix;  // the K-th largest key; `need` (>= 1) elements equal to it are wanted, lowest indices first
-  // ---- equal elements: rank by index order (threads own contiguous index ranges) ----
-  unsigned eq = 0;
-  for (int i = i0; i < i1; ++i) eq += topk_key(row[i]) == thr;
-  sh_eq_base[tid + 1] = eq;
   if (tid == 0) {
-    sh_eq_base[0] = 0;
     sh_cnt = 0;
+    sh_eq_total = 0;
   }
   __syncthreads();
-  if (tid == 0)
-    for (int t = 1; t <= 1024; ++t) sh_eq_base[t] += sh_eq_base[t - 1];  // (1024 adds, once per row)
+  // ---- everything above the threshold; count of the elements equal to it ----
+  {
+    unsigned eq = 0;
+    for (int i = tid; i < L; i += 8 * 1024) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (i + u * 1024 < L) ? row[i + u * 1024] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i + u * 1024 >= L) continue;
+        const unsigned k = topk_key(v[u]);
+        if (k == thr) {  // (an equal element is kept for now: at most 64 slots are ever used; the tie path below starts over)
+          ++eq;
+          const unsigned slot = atomicAdd(&sh_cnt, 1u);
+          if (slot < 64) {
+            sel_key[slot] = k;
+            sel_idx[slot] = i + u * 1024;
+          }
+        } else if (k > thr) {
+          const unsigned slot = atomicAdd(&sh_cnt, 1u);
+          if (slot < 64) {
+            sel_key[slot] = k;
+            sel_idx[slot] = i + u * 1024;
+          }
+        }
+      }
+    }
+    if (eq) atomicAdd(&sh_eq_total, eq);
+  }
   __syncthreads();
-  unsigned eq_rank = sh_eq_base[tid];
-  for (int i = i0; i < i1; ++i) {
-    const unsigned k = topk_key(row[i]);
-    bool take = k > thr;
-    if (k == thr) take = eq_rank++ < need;
-    if (take) {
-      const unsigned slot = atomicAdd(&sh_cnt, 1u);
-      if (slot < 64) {
-        sel_key[slot] = k;
+  if (sh_eq_total != need) {  // a tie across the last place (rare): start the collection over
+    __syncthreads();
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < L; i += 1024) {
+      const unsigned k = topk_key(row[i]);
+      if (k > thr) {
+        const unsigned slot = atomicAdd(&sh_cnt, 1u);
+        sel_key[slot] = k;  // (fewer than K of them)
         sel_idx[slot] = i;
       }
     }
+    __syncthreads();
+  }
+  if (sh_eq_total == need) {  // the usual case: no tie across the last place -- everything was collected in the pass above
+  } else {  // a tie across the last place: the lowest indices win -- threads take contiguous index ranges and rank their equals in order
+    const int chunk = (L + 1023) / 1024, i0 = tid * chunk, i1 = min(i0 + chunk, L);
+    unsigned eq = 0;
+    for (int i = i0; i < i1; ++i) eq += topk_key(row[i]) == thr;
+    sh_eq_base[tid + 1] = eq;
+    if (tid == 0) sh_eq_base[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+      for (int t = 1; t <= 1024; ++t) sh_eq_base[t] += sh_eq_base[t - 1];
+    __syncthreads();
+    unsigned eq_rank = sh_eq_base[tid];
+    for (int i = i0; i < i1 && eq_rank < need; ++i)
+      if (topk_key(row[i]) == thr) {
+        ++eq_rank;
+        const unsigned slot = atomicAdd(&sh_cnt, 1u);
+        sel_key[slot] = thr;
+        sel_idx[slot] = i;
+      }
   }
   __syncthreads();
   // ---- order the K survivors: descending key, ascending index ----
