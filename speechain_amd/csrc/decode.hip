@@ -279,21 +279,36 @@ __global__ __launch_bounds__(256) void ctc_psi_kernel(const float* x, const int*
   for (int r = 0; r < RPB; ++r) {
     const long long lastc = plen > 0 ? last[n0 + r] : 0;  // (the reference takes token 0 for the empty prefix, :84)
     phi[r] = s_phi + (r * 2 + (c == lastc ? 1 : 0)) * T;
-    // running logsumexp (m, s), first term r^n_{start-1}(h)
-    m[r] = (plen == 0) ? ((0 < len) ? xc[0] : pad_x) : CTC_IMPOSSIBLE;
-    s[r] = 1.f;
+    m[r] = (plen == 0) ? ((0 < len) ? xc[0] : pad_x) : CTC_IMPOSSIBLE;  // first term r^n_{start-1}(h)
   }
-  for (int t = start; t < T; ++t) {
-    const float xl = (t < len) ? xc[(long long)t * V] : pad_x;
+  // two sweeps over the frames instead of a running (max, sum) pair: the maximum first (add + max per term), then the sum of
+  // exp(term - max) (add, sub, exp, add) -- about a third fewer vector instructions per term, and x comes out of L2 the second time
+  for (int t0 = start; t0 < T; t0 += 8) {  // (eight frames' loads in flight per lane)
+    float xl[8];
 #pragma unroll
-    for (int r = 0; r < RPB; ++r) {
-      const float v = phi[r][t - 1] + xl;
-      const float hi = fmaxf(m[r], v), lo = fminf(m[r], v);
-      // (m, s) <- logsumexp step: s' = s * exp(m - hi) + exp(v - hi), one of the two factors being exp(0)
-      const float e = __expf(lo - hi);
-      s[r] = (v > m[r]) ? fmaf(s[r], e, 1.f) : s[r] + e;
-      m[r] = hi;
-    }
+    for (int u = 0; u < 8; ++u) xl[u] = (t0 + u < len) ? xc[(long long)(t0 + u) * V] : pad_x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + u < T) {
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) m[r] = fmaxf(m[r], phi[r][t0 + u - 1] + xl[u]);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    const float first = (plen == 0) ? ((0 < len) ? xc[0] : pad_x) : CTC_IMPOSSIBLE;
+    s[r] = __expf(first - m[r]);
+  }
+  for (int t0 = start; t0 < T; t0 += 8) {
+    float xl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xl[u] = (t0 + u < len) ? xc[(long long)(t0 + u) * V] : pad_x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + u < T) {
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) s[r] += __expf(phi[r][t0 + u - 1] + xl[u] - m[r]);
+      }
   }
 #pragma unroll
   for (int r = 0; r < RPB; ++r) {

@@ -163,3 +163,40 @@ def test_topk_rows_against_torch(R, L, K):
         eq_all = (x[r].cpu() == last).nonzero().flatten()
         taken = i[v == last]
         assert torch.equal(taken.sort().values, eq_all[: len(taken)])
+
+
+def test_asr_encoder_sequencing_and_inference():
+    """ASREncoder built from recipe-style dictionaries (frontend -> normalisation -> prenet -> encoder; SpecAugment only in training)
+    equals its parts applied by hand, and feeds beam_searching through the ARASRDecoder surface end to end (waveforms in, token ids out)."""
+    from speechain_amd import functional as Fn
+    from speechain_amd.infer_func.beam_search import beam_searching
+    from speechain_amd.module.decoder.ar_asr import ARASRDecoder
+    from speechain_amd.module.encoder.asr import ASREncoder
+    from speechain_amd.module.postnet.token import TokenPostnet
+
+    torch.manual_seed(0)
+    conf = dict(frontend=dict(type="frontend.speech2mel.Speech2MelSpec", conf=dict(n_mels=80, hop_length=0.010, win_length=0.025, sr=16000, preemphasis=0.97)),
+                normalize=dict(norm_type="utterance"), specaug=dict(time_warp=False),
+                prenet=dict(type="prenet.conv2d.Conv2dPrenet", conf=dict(conv_dims=[8, 8], lnr_dims=128)),
+                encoder=dict(type="transformer.encoder.TransformerEncoder",
+                             conf=dict(num_heads=2, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0)))
+    enc = ASREncoder(**conf).cuda().eval()
+    wave = (torch.randn(2, 8000, 1) * 0.1).cuda()
+    wave_len = torch.tensor([8000, 6400]).cuda()
+    with torch.no_grad():
+        out, mask, _, _ = enc(wave, wave_len.clone())
+        f, fl = enc.frontend(wave, wave_len.clone())
+        f, fl = enc.normalize(f, fl)
+        f, fl = enc.prenet(f, fl)
+        from speechain_amd.utilbox.train_util import make_mask_from_len
+        want, _, _, _ = enc.encoder(f, make_mask_from_len(fl, max_len=f.size(1)).cuda())
+    assert torch.equal(out, want) and out.shape[0] == 2 and mask.shape == (2, 1, out.size(1))
+    assert hasattr(enc, "specaug") and enc.output_size == 128
+    V = 19
+    dec = ARASRDecoder(vocab_size=V, embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=128)),
+                       decoder=dict(type="transformer.decoder.TransformerDecoder", conf=dict(num_heads=2, num_layers=1, fdfwd_dim=64))).cuda().eval()
+    ctc = TokenPostnet(input_size=128, vocab_size=V).cuda().eval()
+    res = beam_searching(enc_feat=out, enc_feat_mask=mask, asr_decode_fn=dec, ctc_decode_fn=ctc, vocab_size=V, beam_size=3, ctc_weight=0.3,
+                         min_f2t_ratio=2.0)
+    assert res["hypo_text"].shape[0] == 2 and int(res["hypo_text_len"].max()) <= out.size(1) // 2
+    assert bool(torch.isfinite(res["hypo_text_confid"]).all())
