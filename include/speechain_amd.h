@@ -308,6 +308,15 @@ int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev
  * The candidate selection of a beam-search step (speechain/infer_func/beam_search.py:419-421: torch.topk over (batch, beam * vocab)). */
 int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream);
 
+/* Candidate scores of a beam-search step (speechain/infer_func/beam_search.py:334-345,401-410) in one pass over the token head's logits:
+ *   cand[n][v] = (1 - ctc_weight) * log_softmax(logits[n] / temperature)[v] + ctc_weight * (psi[n][v] - psi_prev[n]) + beam_score[n],
+ * the blank column of the attention term forced to -1e20 when psi is given (:339).  logits (N, V) f32 / bf16 (dtype 0 / 1), row stride ld;
+ * psi (N, V), psi_prev (N) may be NULL; eos_score / other_max (N) (the mixed score of <eos> and the best other one, for <eos> filtering
+ * :455-462) may be NULL. */
+int sc_beam_candidates(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
+                       float* cand, float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank, int eos,
+                       hipStream_t stream);
+
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);
  * lse[r] is kept for the backward pass, which writes dlogits = grow[r]/temperature * (softmax - (1-eps)*onehot - eps/V). */

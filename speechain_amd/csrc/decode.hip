@@ -625,3 +625,77 @@ SC_API int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float
   SC_LAUNCH_CHECK("topk_rows_kernel");
   return SC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Candidate scores of a beam-search step in one pass over the token head's logits (speechain/infer_func/beam_search.py:334-345,401-410):
+//   cand[n][v] = (1 - w) * log_softmax(logits[n] / temperature)[v] + w * (psi[n][v] - psi_prev[n]) + beam_score[n]
+// with the blank column of the attention term forced to -1e20 when CTC scores take part (:339), plus -- for <eos> filtering (:455-462) --
+// the row's <eos> score and the best other score (both of the mixed token scores, before beam_score is added).
+// One workgroup per hypothesis row; the row is read three times out of L1 / L2 (maximum, sum of exponentials, output).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void beam_candidates_kernel(const T* logits, long long ld, const float* psi, const float* psi_prev,
+                                                              const float* beam_score, float* cand, float* eos_score, float* other_max,
+                                                              int V, float inv_temp, float w, int blank, int eos) {
+  __shared__ float red[8];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const T* row = logits + (long long)n * ld;
+  float m = -INFINITY;
+  for (int v = tid; v < V; v += 256) m = fmaxf(m, Elem<T>::ld(row + v) * inv_temp);
+  m = sc_wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int v = tid; v < V; v += 256) s += __expf(Elem<T>::ld(row + v) * inv_temp - m);
+  s = sc_wave_sum(s);
+  if (lane == 0) red[4 + wv] = s;
+  __syncthreads();
+  const float lse = m + __logf(red[4] + red[5] + red[6] + red[7]);
+  const float bs = beam_score[n];
+  const float pp = (psi && psi_prev) ? psi_prev[n] : 0.f;
+  float best_other = -INFINITY;
+  for (int v = tid; v < V; v += 256) {
+    float t = Elem<T>::ld(row + v) * inv_temp - lse;
+    if (psi) {
+      if (v == blank) t = CTC_IMPOSSIBLE;
+      t = (1.f - w) * t + w * (psi[(long long)n * V + v] - pp);
+    }
+    cand[(long long)n * V + v] = t + bs;
+    if (v == eos) {
+      if (eos_score) eos_score[n] = t;
+    } else {
+      best_other = fmaxf(best_other, t);
+    }
+  }
+  if (other_max) {
+    __syncthreads();
+    best_other = sc_wave_max(best_other);
+    if (lane == 0) red[wv] = best_other;
+    __syncthreads();
+    if (tid == 0) other_max[n] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+}
+
+}  // namespace
+
+// cand (N, V) f32 as above.  dtype of logits: 0 = f32, 1 = bf16, row stride ld.  psi (N, V) / psi_prev (N) may be NULL (no CTC term / first
+// step); eos_score, other_max (N) may be NULL.
+SC_API int sc_beam_candidates(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
+                              float* cand, float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank,
+                              int eos, hipStream_t stream) {
+  SC_CHECK_ARG(logits && beam_score && cand, "sc_beam_candidates: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_beam_candidates: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(N >= 1 && N <= 0x7fffffff && V >= 1 && ld >= V && temperature > 0.f && blank >= 0 && blank < V && eos >= 0 && eos < V,
+               "sc_beam_candidates: bad sizes N=%d V=%d", N, V);
+  if (dtype == 0)
+    hipLaunchKernelGGL(beam_candidates_kernel<float>, dim3(N), dim3(256), 0, stream, (const float*)logits, ld, psi, psi_prev, beam_score, cand,
+                       eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos);
+  else
+    hipLaunchKernelGGL(beam_candidates_kernel<unsigned short>, dim3(N), dim3(256), 0, stream, (const unsigned short*)logits, ld, psi, psi_prev,
+                       beam_score, cand, eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos);
+  SC_LAUNCH_CHECK("beam_candidates_kernel");
+  return SC_OK;
+}

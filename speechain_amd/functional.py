@@ -1606,3 +1606,19 @@ def topk_rows(x: torch.Tensor, k: int):
     idx = torch.empty(R, k, dtype=torch.long, device=x.device)
     lib.call("sc_topk_rows", _p(x), x.stride(0), R, L, int(k), _p(vals), _p(idx), stream())
     return vals, idx
+
+
+def beam_candidates(logits: torch.Tensor, beam_score: torch.Tensor, temperature: float, psi=None, psi_prev=None, ctc_weight: float = 0.0,
+                    blank: int = 0, eos: int = 0, want_eos_stats: bool = False):
+    """(N, V) f32 candidate scores of a beam-search step from the token head's logits (sc_beam_candidates): length-V log-softmax at
+    `temperature`, mixed with the CTC prefix scores `psi - psi_prev` when given, plus the rows' running scores.  With `want_eos_stats`
+    also the mixed <eos> score and the best other score of every row."""
+    require_gpu(logits, "beam_candidates")
+    N, V = logits.shape
+    assert logits.stride(1) == 1 and beam_score.dtype == torch.float32
+    cand = torch.empty(N, V, dtype=torch.float32, device=logits.device)
+    es = torch.empty(N, dtype=torch.float32, device=logits.device) if want_eos_stats else None
+    om = torch.empty(N, dtype=torch.float32, device=logits.device) if want_eos_stats else None
+    lib.call("sc_beam_candidates", dcode(logits), _p(logits), logits.stride(0), _p(psi), _p(psi_prev), _p(beam_score), _p(cand), _p(es), _p(om),
+             N, V, float(temperature), float(ctc_weight), int(blank), int(eos), stream())
+    return cand, es, om

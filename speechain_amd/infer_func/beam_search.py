@@ -111,19 +111,18 @@ class _Session:
                 self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
             self.cache.pos = pos
             logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
-            nts = torch.log_softmax(logits.float() / self.temperature, dim=-1)
+            psi = None
             if self.ctc:
-                nts[:, self.pad] = minus_inf  # the blank is never a token (:339)
                 psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
                                            beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
-                nts = (1 - w) * nts + w * (psi - self.psi_sel[:, None] if pos > 0 else psi)
-            cand = (nts + self.scores[:, None]).view(B, beam * V)
-            top_scores, top_ids = Fn.topk_rows(cand, 2 * beam) if 2 * beam <= 64 else torch.topk(cand, 2 * beam, dim=1, largest=True, sorted=True)
+            # log-softmax of the token head, CTC mixing (:334-345) and the rows' running scores in one kernel
+            cand, eos_score, other_max = Fn.beam_candidates(logits, self.scores, self.temperature, psi, self.psi_sel if (self.ctc and pos > 0) else None,
+                                                            w, self.pad, self.sos_eos, want_eos_stats=self.eos_filtering)
+            top_scores, top_ids = Fn.topk_rows(cand.view(B, beam * V), 2 * beam) if 2 * beam <= 64 else \
+                torch.topk(cand.view(B, beam * V), 2 * beam, dim=1, largest=True, sorted=True)
             fetch = [top_scores.to(torch.float64), top_ids.to(torch.float64)]
             if self.eos_filtering:
-                others = nts.clone()
-                others[:, self.sos_eos] = float("-inf")
-                fetch += [nts[:, self.sos_eos].view(B, beam).to(torch.float64), others.max(dim=-1).values.view(B, beam).to(torch.float64)]
+                fetch += [eos_score.view(B, beam).to(torch.float64), other_max.view(B, beam).to(torch.float64)]
             self.pack.copy_(torch.cat(fetch, dim=1))
             self.prev_tokens.copy_(self.tokens)
 
