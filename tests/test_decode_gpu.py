@@ -200,3 +200,65 @@ def test_asr_encoder_sequencing_and_inference():
                          min_f2t_ratio=2.0)
     assert res["hypo_text"].shape[0] == 2 and int(res["hypo_text_len"].max()) <= out.size(1) // 2
     assert bool(torch.isfinite(res["hypo_text_confid"]).all())
+
+
+def test_ctc_prefix_scorer_medium_size_against_oracle():
+    """CTCPrefixScorer on the HIP kernels vs the oracle's restatement of the reference at sizes that exercise what the small fixture cannot:
+    more frames than lanes (several frames per lane in the scans), four rows of a sentence per workgroup, ragged lengths, six steps with
+    random parents and tokens (repeated last labels included)."""
+    from oracle import decode_ref as D
+    from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
+
+    gen = torch.Generator().manual_seed(11)
+    B, beam, T, V = 3, 4, 150, 300
+    x = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 2.0, dim=-1).repeat_interleave(beam, dim=0)
+    lens = torch.tensor([150, 97, 64]).repeat_interleave(beam)
+    ref = D.CtcPrefixScores(x, lens, B, beam, blank_index=0, eos_index=V - 1)
+    sc = CTCPrefixScorer(x=x.cuda(), enc_lens=lens.cuda(), batch_size=B, beam_size=beam, blank_index=0, eos_index=V - 1)
+    text = torch.zeros(B * beam, 0, dtype=torch.long)
+    s_ref, s_gpu = None, None
+    for step in range(6):
+        p_ref, s_ref = ref.forward_step(text, s_ref)
+        p_gpu, s_gpu = sc.forward_step(text.cuda(), s_gpu)
+        fin = p_ref > -1e19
+        assert torch.equal(fin, p_gpu.cpu() > -1e19), step
+        err = float((p_gpu.cpu()[fin] - p_ref[fin]).abs().max())
+        assert err < 2e-3, (step, err)  # (sums of up to 150 terms of magnitude up to ~1e3 in f32, two different summation orders)
+        parents = (torch.arange(B)[:, None] * beam + torch.randint(0, beam, (B, beam), generator=gen)).reshape(-1)
+        tokens = torch.randint(1, V - 1, (B * beam,), generator=gen)
+        if step >= 1:
+            tokens[::3] = text[parents[::3], -1]  # repeat the parent's last label: the phi = r^b branch
+        text = torch.cat([text[parents], tokens[:, None]], dim=1)
+        tok_idx = tokens.view(B, beam) + (torch.arange(beam) * V)[None, :]
+        s_ref = ref.permute_mem(s_ref, parents, tok_idx)
+        s_gpu = sc.permute_mem(s_gpu, parents.cuda(), tok_idx.cuda())
+        fin_r = s_ref[0] > -1e19
+        assert torch.equal(fin_r, s_gpu[0].cpu() > -1e19), step
+        assert float((s_gpu[0].cpu()[fin_r] - s_ref[0][fin_r]).abs().max()) < 2e-3, step
+
+
+def test_cached_and_prefix_beam_search_agree_at_recipe_width():
+    """d 512, 8 heads, V 5000, beam 16, 100 frames, CTC weight 0.2 (two decoder layers to keep it short): the cached path (eager, then replayed)
+    and the stateless calling convention on the same HIP kernels pick the same hypotheses, f32 mode."""
+    from speechain_amd.infer_func.beam_search import beam_searching
+    from speechain_amd.module.decoder.ar_asr import ARASRDecoder
+    from speechain_amd.module.postnet.token import TokenPostnet
+    from speechain_amd.utilbox.train_util import make_mask_from_len
+
+    torch.manual_seed(4)
+    V = 5000
+    dec = ARASRDecoder(vocab_size=V, embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=512)),
+                       decoder=dict(type="transformer.decoder.TransformerDecoder",
+                                    conf=dict(num_heads=8, num_layers=2, fdfwd_dim=2048, fdfwd_activation="GELU", emb_scale=False))).cuda().eval()
+    with torch.no_grad():
+        dec.postnet.linear.weight.mul_(3.0)  # sharper token distributions: well-separated candidates
+    ctc = TokenPostnet(input_size=512, vocab_size=V).cuda().eval()
+    enc = torch.randn(2, 100, 512).cuda()
+    mask = make_mask_from_len(torch.tensor([100, 77]), max_len=100).cuda()
+    kw = dict(vocab_size=V, beam_size=16, ctc_weight=0.2, min_f2t_ratio=4.0)
+    want = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=lambda enc_feat, enc_feat_mask, text, text_len:
+                          dec(enc_feat, enc_feat_mask, text, text_len), ctc_decode_fn=ctc, **kw)
+    for _ in range(2):  # eager, then replayed
+        got = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=dec, ctc_decode_fn=ctc, **kw)
+        assert torch.equal(got["hypo_text"], want["hypo_text"]) and torch.equal(got["hypo_text_len"], want["hypo_text_len"])
+        assert torch.allclose(got["hypo_text_confid"], want["hypo_text_confid"], atol=1e-3)
