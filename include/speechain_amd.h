@@ -67,6 +67,19 @@ int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, int B, 
                            float* out_linear, float lin_clamp, int lin_logging, float lin_log_div,
                            long long* feat_len, int T, const float* mel_image, hipStream_t stream);
 
+/* Wide transforms (n_fft >= 512; the FastSpeech2 preset has 1024) as three launches instead of sc_frontend_logmel_fwd's one:
+ *   sc_frontend_frames       frames (B T, krows) f32, krows = n_fft rounded up to even: pre-emphasis, reflect padding, tail zeroing
+ *                            (speech2linear.py:167-173 and the framing inside torch.stft, :198)
+ *   sc_gemm (dtype 0, tb 1)  spec (B T, 32 * sc_frontend_num_tiles(n_fft)) = frames x the basis of sc_frontend_basis_init
+ *   sc_frontend_spec_finish  power / magnitude, mel, clamp / log, energy, lengths: the outputs of sc_frontend_logmel_fwd
+ * The LDS-staged exact-f32 product runs the 1024-point transform of a 32 x 7.4 s batch in 0.6 ms where the one-launch kernel takes 1.35 ms. */
+int sc_frontend_frames(const float* wave, const long long* wave_len, int B, int T_w, long long wave_stride, int use_preemph, float preemph,
+                       int n_fft, int hop, int center, int T, float* frames, hipStream_t stream);
+int sc_frontend_spec_finish(const float* spec, const long long* wave_len, int B, int T_w, int n_fft, int hop, int center, const float* melw,
+                            const int* band_lo, const int* band_hi, int n_mels, int mag_spec, float clamp, int logging, float log_div,
+                            float* out_feat, float* out_energy, float* out_linear, float lin_clamp, int lin_logging, float lin_log_div,
+                            long long* feat_len, int T, hipStream_t stream);
+
 /* Stand-alone mel filterbank + clamp/log over an (N, NB) spectrogram: LinearSpec2MelSpec.forward
  * (speechain/module/frontend/linear2mel.py:163-189) when it is called on its own. */
 int sc_mel_log_fwd(const float* spec, long long N, int NB, const float* melw, const int* band_lo, const int* band_hi,

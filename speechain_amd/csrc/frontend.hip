@@ -259,6 +259,60 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendArgs p) {
 }
 
 
+// ---- wide transforms (n_fft >= 512) as a matrix product of the library: frames -> sc_gemm (exact f32) -> finish -------------------
+// frontend_kernel<FT> above reads its B operand (the basis) one float per lane and MFMA from L2: 32 TFLOP/s at n_fft = 1024 (1.35 ms for the
+// FastSpeech2 batch), where the LDS-staged exact-f32 GEMM kernel of csrc/gemm.hip runs the same product at 76 TFLOP/s.  The three steps:
+//   frontend_frames_kernel       frames (B T, n_fft): pre-emphasis, reflect padding, tail zeroing -- the sample image of stage_samples, written out
+//   sc_gemm (f32)                spec (B T, 32 NT) = frames x basis  ([16 cos | 16 sin] column tiles, the window folded into the basis)
+//   frontend_spec_finish_kernel  power / magnitude of 32 frames into the LDS image the shared epilogue reads (mel, log, energy, copy-out)
+__global__ __launch_bounds__(256) void frontend_frames_kernel(FrontendArgs p, float* frames) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const float* x = p.wave + (long long)b * p.wave_stride;
+  const long long wlen = p.wave_len[b];
+  const int len = (int)(wlen < p.T_w ? wlen : p.T_w);
+  const int limit = p.use_preemph ? len : p.T_w;
+  const float negc = p.use_preemph ? -p.preemph : 0.f;
+  float* dst = frames + ((long long)b * p.T + t) * p.krows;
+  const int base = t * p.hop - p.pad;
+  for (int k = threadIdx.x; k < p.krows; k += 256) {
+    int n = base + k;
+    const bool inside = k < p.n_fft;
+    n = n < 0 ? -n : n;
+    n = n >= p.T_w ? 2 * (p.T_w - 1) - n : n;
+    const bool take = inside && n < limit;
+    n = take ? n : 0;
+    const float c = x[n], q = x[n > 0 ? n - 1 : 0];
+    dst[k] = fmaf(negc, (p.use_preemph && take && n > 0) ? q : 0.f, take ? c : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void frontend_spec_finish_kernel(FrontendArgs p, const float* spec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const long long wlen = p.wave_len[b];
+  long long flen_ll = floordiv_ll(wlen + 2LL * p.pad - p.n_fft, p.hop) + 1;
+  if (blockIdx.x == 0 && tid == 0) p.feat_len[b] = flen_ll;
+  const int flen = (int)(flen_ll < 0 ? 0 : (flen_ll > p.T ? p.T : flen_ll));
+  float* P = smem + p.off_P;
+  const int NC = p.NT * 32;
+  // column tile j of spec holds cos (re) of bins 16 j .. 16 j + 15 in its first 16 columns and sin (im) in the other 16
+  for (int e = tid; e < 32 * p.NT * 16; e += 256) {
+    const int f = e / (p.NT * 16), c = e - f * (p.NT * 16);
+    const int tile = c >> 4, i = c & 15;
+    float v = 0.f;
+    if (t0 + f < p.T) {
+      const float* srow = spec + ((long long)b * p.T + t0 + f) * NC + tile * 32;
+      const float re = srow[i], im = srow[16 + i];
+      v = re * re + im * im;
+    }
+    P[f * p.PS + c] = p.mag_spec ? sqrtf(v) : v;
+  }
+  __syncthreads();
+  frontend_epilogue<32>(p, P, smem + p.off_O, b, t0, flen, tid, lane, wid);
+}
+
 // ---- n_fft = 400: Good-Thomas (prime-factor) two-stage DFT, 400 = 16 x 25 with gcd 1 -> no twiddle factors --------------
 //   input index  n = (25 n1 + 16 n2) mod 400,   output index  k = (225 k1 + 176 k2) mod 400   (CRT maps)
 //   stage 1: 25-point real-input DFTs along n2 for each n1 (k2 = 0..12 suffice: conjugate symmetry)
@@ -883,5 +937,55 @@ SC_API int sc_frontend_logmel_fwd(const float* wave, const long long* wave_len, 
     hipLaunchKernelGGL(frontend_kernel<1>, grid, dim3(256), smem, stream, a);
   }
   SC_LAUNCH_CHECK("frontend_kernel");
+  return SC_OK;
+}
+
+
+// ---- wide transforms through the library's f32 GEMM (see frontend_frames_kernel) ---------------------------------------------------
+// frames (B T, krows) f32 with krows = n_fft rounded up to even: what sc_gemm multiplies with the basis of sc_frontend_basis_init.
+SC_API int sc_frontend_frames(const float* wave, const long long* wave_len, int B, int T_w, long long wave_stride, int use_preemph,
+                              float preemph, int n_fft, int hop, int center, int T, float* frames, hipStream_t stream) {
+  SC_CHECK_ARG(wave && wave_len && frames, "sc_frontend_frames: null pointer");
+  SC_CHECK_ARG(B >= 1 && B <= 65535 && T_w >= 1 && n_fft >= 2 && hop >= 1 && wave_stride >= T_w, "sc_frontend_frames: bad sizes");
+  const int pad = center ? n_fft / 2 : 0;
+  SC_CHECK_ARG((!center || pad < T_w) && T_w + 2 * pad >= n_fft && T == (T_w + 2 * pad - n_fft) / hop + 1, "sc_frontend_frames: T=%d does not match the batch", T);
+  FrontendArgs a{};
+  a.wave = wave; a.wave_len = wave_len; a.wave_stride = wave_stride; a.T_w = T_w;
+  a.use_preemph = use_preemph; a.preemph = preemph;
+  a.n_fft = n_fft; a.krows = (n_fft + 1) & ~1; a.hop = hop; a.pad = pad; a.T = T;
+  hipLaunchKernelGGL(frontend_frames_kernel, dim3(T, B), dim3(256), 0, stream, a, frames);
+  SC_LAUNCH_CHECK("frontend_frames_kernel");
+  return SC_OK;
+}
+
+// spec (B T, 32 * sc_frontend_num_tiles(n_fft)) f32 = frames x basis -> the outputs of sc_frontend_logmel_fwd (same arguments, same
+// meaning; mel_image unused).
+SC_API int sc_frontend_spec_finish(const float* spec, const long long* wave_len, int B, int T_w, int n_fft, int hop, int center,
+                                   const float* melw, const int* band_lo, const int* band_hi, int n_mels, int mag_spec, float clamp,
+                                   int logging, float log_div, float* out_feat, float* out_energy, float* out_linear, float lin_clamp,
+                                   int lin_logging, float lin_log_div, long long* feat_len, int T, hipStream_t stream) {
+  SC_CHECK_ARG(spec && wave_len && feat_len, "sc_frontend_spec_finish: null pointer");
+  SC_CHECK_ARG(B >= 1 && B <= 65535 && T >= 1 && n_fft >= 2 && hop >= 1, "sc_frontend_spec_finish: bad sizes");
+  SC_CHECK_ARG(out_feat == nullptr || (melw && band_lo && band_hi && n_mels >= 1), "sc_frontend_spec_finish: mel output needs melw/bands");
+  SC_CHECK_ARG(out_feat || out_linear || out_energy, "sc_frontend_spec_finish: no output requested");
+  FrontendArgs a{};
+  a.wave_len = wave_len; a.T_w = T_w;
+  a.n_fft = n_fft; a.krows = (n_fft + 1) & ~1; a.hop = hop; a.pad = center ? n_fft / 2 : 0; a.T = T;
+  a.NT = sc_frontend_num_tiles(n_fft); a.NB = n_fft / 2 + 1;
+  a.melw = melw; a.band_lo = band_lo; a.band_hi = band_hi; a.n_mels = out_feat ? n_mels : 0;
+  a.mag_spec = mag_spec; a.clamp = clamp; a.logging = logging; a.log_div = log_div;
+  a.log_scale = (float)(0.69314718055994530942 / (double)log_div);
+  a.out_feat = out_feat; a.out_energy = out_energy; a.out_linear = out_linear;
+  a.lin_clamp = lin_clamp; a.lin_logging = lin_logging; a.lin_log_div = lin_log_div;
+  a.feat_len = feat_len;
+  a.PS = a.NT * 16 + 1;
+  a.OS = (n_mels > 0 ? n_mels : 1) | 1;
+  a.off_P = 0;
+  a.off_O = (32 * a.PS + 3) & ~3;
+  const size_t smem = (size_t)(a.off_O + (out_feat ? 32 * a.OS : 0)) * sizeof(float);
+  SC_CHECK_ARG(smem <= 160 * 1024, "sc_frontend_spec_finish: n_fft=%d needs %zu B of LDS (> 160 KiB)", n_fft, smem);
+  SC_HIP(hipFuncSetAttribute((const void*)frontend_spec_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(frontend_spec_finish_kernel, dim3(sc_cdiv(T, 32), B), dim3(256), smem, stream, a, spec);
+  SC_LAUNCH_CHECK("frontend_spec_finish_kernel");
   return SC_OK;
 }

@@ -9,6 +9,7 @@ Differences kept on purpose: ``speech_len`` is NOT mutated in place (the referen
 caller's tensor, :202); the output does not carry autograd history (the frontend has no trainable parameter).
 """
 import math
+import os
 
 import torch
 
@@ -81,6 +82,21 @@ def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPl
     if want_energy:
         energy = torch.empty(B, T, dtype=torch.float32, device=dev)
     feat_len = torch.empty(B, dtype=torch.int64, device=dev)
+    log_div = 1.0 if log_base is None else math.log(log_base)
+    lin_log_div = 1.0 if lin_log_base is None else math.log(lin_log_base)
+    if n_fft >= 512 and n_fft % 2 == 0 and os.environ.get("SC_FRONTEND_GEMM", "1") != "0":
+        # wide transform: framing, the library's exact-f32 GEMM against the windowed-DFT basis, finish (csrc/frontend.hip)
+        nc = 32 * lib.value("sc_frontend_num_tiles", n_fft)
+        frames = torch.empty(B * T, n_fft, dtype=torch.float32, device=dev)
+        lib.call("sc_frontend_frames", ptr(wave), ptr(wave_len), B, T_w, wave.stride(0), 1 if preemphasis is not None else 0,
+                 float(preemphasis or 0.0), n_fft, hop, 1 if center else 0, T, ptr(frames), stream())
+        spec = torch.empty(B * T, nc, dtype=torch.float32, device=dev)
+        lib.call("sc_gemm", 0, 0, 1, ptr(frames), ptr(plan.basis(dev)), ptr(spec), B * T, nc, n_fft, n_fft, nc, nc, 1, 1, 0, 0, 0, 0, 0, 0, 1.0,
+                 None, 0, None, None, 0, 0, 0.0, None, 0, 0, 0, stream())
+        lib.call("sc_frontend_spec_finish", ptr(spec), ptr(wave_len), B, T_w, n_fft, hop, 1 if center else 0, ptr(melw), ptr(lo), ptr(hi),
+                 n_mels, 1 if mag_spec else 0, float(clamp), 1 if logging else 0, log_div, ptr(mel), ptr(energy), ptr(lin), float(lin_clamp),
+                 1 if lin_logging else 0, lin_log_div, ptr(feat_len), T, stream())
+        return mel, lin, energy, feat_len
     lib.call("sc_frontend_logmel_fwd", ptr(wave), ptr(wave_len), B, T_w, wave.stride(0),
              1 if preemphasis is not None else 0, float(preemphasis or 0.0), n_fft, hop, 1 if center else 0,
              ptr(plan.basis(dev)), ptr(melw), ptr(lo), ptr(hi), n_mels, 1 if mag_spec else 0, float(clamp),
