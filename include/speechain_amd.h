@@ -80,6 +80,22 @@ int sc_frontend_spec_finish(const float* spec, const long long* wave_len, int B,
                             float* out_feat, float* out_energy, float* out_linear, float lin_clamp, int lin_logging, float lin_log_div,
                             long long* feat_len, int T, hipStream_t stream);
 
+/* ---- Griffin-Lim waveform recovery (csrc/griffinlim.hip): Speech2LinearSpec.recover (speechain/module/frontend/speech2linear.py:252-351).
+ * The reference delegates the iteration to torchaudio.transforms.GriffinLim (:279-293; third party, absent); its published algorithm runs
+ * here as products of sc_gemm (dtype 0) with two bases plus these element-wise / gather kernels:
+ *   sc_istft_basis_init   inverse basis (32 * sc_frontend_num_tiles(n_fft), krows): irfft weights / n_fft times the centred synthesis window
+ *   sc_istft_overlap_add  frames (B T, krows) = spectrum x inverse basis -> out (B, L): overlap-add divided by the window envelope, the
+ *                         n_fft / 2 reflect padding of center = true trimmed (L <= hop (T - 1))
+ *   sc_gl_phase_update    mode 0: spec = mag * initial phases; mode 1: A = rebuilt - coef * tprev, spec = mag * A / (|A| + 1e-16),
+ *                         tprev <- rebuilt (coef = momentum / (1 + momentum)); spectra in the [16 re | 16 im] column-tile layout (M, 32 NT)
+ *   sc_fir_causal         y[n] = sum_{k < taps} c^k x[n - k]: the sliding-window inverse pre-emphasis (:301-345) */
+int sc_istft_basis_init(const float* window, int win_length, int n_fft, float* inv_basis, hipStream_t stream);
+int sc_istft_overlap_add(const float* frames, const float* window, int win_length, int n_fft, int hop, int B, int T, float* out, int L,
+                         long long out_stride, hipStream_t stream);
+int sc_gl_phase_update(int mode, const float* mag, const float* angle_re, const float* angle_im, const float* rebuilt, float* tprev,
+                       float* spec, long long M, int n_fft, float coef, hipStream_t stream);
+int sc_fir_causal(const float* x, long long x_stride, float* y, long long y_stride, int B, int L, float c, int taps, hipStream_t stream);
+
 /* Stand-alone mel filterbank + clamp/log over an (N, NB) spectrogram: LinearSpec2MelSpec.forward
  * (speechain/module/frontend/linear2mel.py:163-189) when it is called on its own. */
 int sc_mel_log_fwd(const float* spec, long long N, int NB, const float* melw, const int* band_lo, const int* band_hi,

@@ -853,3 +853,54 @@ def fastspeech2_forward_loss(text: Tensor, text_len: Tensor, duration: Tensor, w
                pred_energy=pred_energy, tgt_energy=tok_energy, pred_dur=pred_dur, used_dur=used, loss=sum(terms.values()), bn_stats=bn_stats)
     out.update({"loss_" + k: v for k, v in terms.items()})
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# f4  recover(): mel -> linear -> waveform    speechain/module/frontend/linear2mel.py:191-224, speech2linear.py:252-351
+# --------------------------------------------------------------------------------------------------
+
+
+def linear2mel_recover(feat: Tensor, feat_len: Tensor, mel_w: Tensor, logging: bool = True, log_base: Optional[float] = 10.0) -> Tensor:
+    """LinearSpec2MelSpec.recover (linear2mel.py:191-224): undo the log, least-squares solve against the (n_mels, n_bins) filterbank
+    (driver 'gels': the minimum-norm solution of the under-determined system), zero the padded frames of shorter utterances, clamp."""
+    x = feat
+    if logging:
+        x = torch.pow(torch.full_like(x, math.e if log_base is None else log_base), x)
+    x = torch.linalg.lstsq(mel_w[None], x.transpose(-2, -1), driver="gels").solution.transpose(-2, -1)
+    x = x.clone()
+    for i in range(len(feat_len)):
+        if feat_len[i] != feat_len.max():
+            x[i, feat_len[i]:] = 0
+    return torch.clamp(x, min=1e-10)
+
+
+def griffin_lim(mag: Tensor, window: Tensor, n_fft: int, hop: int, win_length: int, n_iter: int, momentum: float, init_angles: Tensor) -> Tensor:
+    """torchaudio.functional.griffinlim as published (torchaudio is absent: this restates the third-party algorithm the reference calls at
+    speech2linear.py:279-293 -- parity unpinned there): mag (B, T, F) magnitudes, init_angles (B, T, F) complex -> (B, hop (T - 1))."""
+    S = mag.transpose(1, 2).to(torch.complex64)  # (B, F, T)
+    angles = init_angles.transpose(1, 2).to(torch.complex64)
+    tprev = torch.zeros_like(angles)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win_length, window=window)
+    for _ in range(n_iter):
+        inv = torch.istft(S * angles, **kw)
+        rebuilt = torch.stft(inv, **kw, center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        angles = rebuilt
+        if momentum:
+            angles = angles - tprev * (momentum / (1 + momentum))
+        angles = angles / (angles.abs() + 1e-16)
+        tprev = rebuilt
+    return torch.istft(S * angles, **kw)
+
+
+def speech2linear_recover_post(wav: Tensor, feat_len: Tensor, hop: int, preemph: Optional[float], winlen: int = 100):
+    """What Speech2LinearSpec.recover does after the Griffin-Lim call (speech2linear.py:294-351): lengths, the sliding-window inverse
+    pre-emphasis X[n] = sum_{k < winlen} c^k Y[n - k], silence beyond each utterance.  wav (B, L) -> ((B, L, 1), wav_len)."""
+    wav_len = (feat_len - 1) * hop
+    assert int(wav_len.max()) == wav.size(1)
+    if preemph is not None:
+        w = torch.pow(torch.full((winlen,), preemph), torch.arange(winlen - 1, -1, -1)).reshape(1, 1, -1)
+        wav = F.conv1d(F.pad(wav.unsqueeze(1), (winlen - 1, 0)), w).squeeze(1)
+    wav = wav.clone()
+    for i in range(len(wav_len)):
+        wav[i, wav_len[i]:] = 0
+    return wav.unsqueeze(-1), wav_len

@@ -57,8 +57,30 @@ class LinearSpec2MelSpec(Module):
         return out, feat_len
 
     def recover(self, feat: torch.Tensor, feat_len: torch.Tensor):
-        raise NotImplementedError("least-squares mel inversion (linear2mel.py:191-224) is outside the accelerated hot "
-                                  "path (SURVEY.md section 8f, row f4).")
+        """(log-)mel -> linear spectrogram (linear2mel.py:191-224): undo the logarithm, solve ``mel_fbanks x = mel`` in the least-squares
+        sense, silence the padded frames of the shorter utterances, clamp at 1e-10.  The reference calls ``torch.linalg.lstsq(driver=
+        'gels')`` on the (n_mels, n_bins) matrix per call: the system is under-determined and of full row rank, so its solution is the
+        minimum-norm one, W^T (W W^T)^-1 mel -- one fixed (n_bins, n_mels) matrix (computed once, in float64) applied by the HIP GEMM."""
+        require_gpu(feat, "LinearSpec2MelSpec.recover")
+        x = feat.float()
+        if self.logging:
+            x = torch.exp(x * math.log(math.e if self.log_base is None else self.log_base))
+        w = self.mel_fbanks.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, "_pinv", None) is None or self._pinv[0] != key:
+            w64 = w.double().cpu()
+            self._pinv = (key, (w64.t() @ torch.linalg.inv(w64 @ w64.t())).float().to(w.device).contiguous())  # (n_bins, n_mels)
+        pinv = self._pinv[1]
+        B, T, M = x.shape
+        x2 = x.reshape(B * T, M).contiguous()
+        out = torch.empty(B * T, self.stft_dim, dtype=torch.float32, device=x.device)
+        lib.call("sc_gemm", 0, 0, 0, ptr(x2), ptr(pinv), ptr(out), B * T, self.stft_dim, M, M, M, self.stft_dim, 1, 1, 0, 0, 0, 0, 0, 0, 1.0,
+                 None, 0, None, None, 0, 0, 0.0, None, 0, 0, 0, stream())
+        out = out.view(B, T, self.stft_dim)
+        flen = feat_len.to(x.device)
+        idx = torch.arange(T, device=x.device)[None, :, None]
+        out = out.masked_fill((idx >= flen[:, None, None]) & (flen != flen.max())[:, None, None], 0.0)
+        return torch.clamp(out, min=1e-10)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(\nstft_dim={self.stft_dim}, n_mels={self.n_mels}, fmin={self.fmin}, "

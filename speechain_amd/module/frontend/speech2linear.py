@@ -45,6 +45,17 @@ class StftPlan:
             self._basis[key] = basis
         return self._basis[key]
 
+    def synthesis(self, device: torch.device):
+        """(window, inverse basis) for the overlap-add inverse transform (csrc/griffinlim.hip), built lazily per device."""
+        key = ("inv", device.type, device.index)
+        if key not in self._basis:
+            win = getattr(torch, f"{self.window}_window")(self.win_length, dtype=torch.float32, device=device)
+            nc = 32 * lib.value("sc_frontend_num_tiles", self.n_fft)
+            inv = torch.empty(nc, (self.n_fft + 1) & ~1, dtype=torch.float32, device=device)
+            lib.call("sc_istft_basis_init", ptr(win), self.win_length, self.n_fft, ptr(inv), stream())
+            self._basis[key] = (win, inv)
+        return self._basis[key]
+
 
 def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPlan, hop: int, center: bool,
                  preemphasis, mag_spec: bool, want_linear: bool, lin_clamp: float = 1e-10, lin_logging: bool = False,
@@ -157,9 +168,72 @@ class Speech2LinearSpec(Module):
             return lin, feat_len, energy, feat_len
         return lin, feat_len
 
-    def recover(self, feat: torch.Tensor, feat_len: torch.Tensor, inv_preemph_winlen: int = 100):
-        raise NotImplementedError("Griffin-Lim waveform recovery (speech2linear.py:252-351) is outside the accelerated "
-                                  "hot path (SURVEY.md section 8f, row f4).")
+    def recover(self, feat: torch.Tensor, feat_len: torch.Tensor, inv_preemph_winlen: int = 100, n_iter: int = 32,
+                momentum: float = 0.99, rand_init: bool = True, _init_angles: torch.Tensor = None):
+        """Waveforms from (un-logged) power / magnitude spectrograms by the Griffin-Lim iteration (speech2linear.py:252-351): feat
+        (B, T, n_fft // 2 + 1) -> (wav (B, hop (T - 1), 1), wav_len = (feat_len - 1) * hop), then the sliding-window inverse pre-emphasis
+        and silence beyond each utterance's length.  The reference calls ``torchaudio.transforms.GriffinLim`` with its defaults (32
+        iterations, momentum 0.99, random initial phases: re, im uniform in [0, 1)); ``n_iter`` / ``momentum`` / ``rand_init`` are those
+        defaults, ``_init_angles`` (B, T, F) complex fixes the start for tests."""
+        assert self.pre_stft_norm is None, "waveform pre-stft normalization cannot be recovered for TTS synthesis."
+        wav = self._griffin_lim(feat, n_iter, momentum, rand_init, _init_angles)
+        B, L = wav.shape
+        dev, hop = wav.device, self.hop_length
+        wav_len = (feat_len.to(dev) - 1) * hop
+        assert int(wav_len.max()) == wav.size(1), "Something wrong happens when calculating the length of synthetic utterances."
+        if self.preemphasis is not None:  # X[n] = sum_k 0.97^k Y[n - k] over a window of inv_preemph_winlen samples (:301-345)
+            out = torch.empty_like(wav)
+            lib.call("sc_fir_causal", ptr(wav), wav.stride(0), ptr(out), out.stride(0), B, L, float(self.preemphasis), int(inv_preemph_winlen),
+                     stream())
+            wav = out
+        idx = torch.arange(L, device=dev)[None, :]
+        wav = wav.masked_fill(idx >= wav_len[:, None], 0.0)
+        return wav.unsqueeze(-1), wav_len
+
+    def _griffin_lim(self, feat: torch.Tensor, n_iter: int, momentum: float, rand_init: bool, _init_angles: torch.Tensor = None):
+        """(B, hop (T - 1)) waveforms whose magnitude spectrograms approach ``feat`` (torchaudio.functional.griffinlim's iteration)."""
+        require_gpu(feat, "Griffin-Lim recovery")
+        if not self.stft_config["center"]:
+            raise NotImplementedError("speechain_amd: Griffin-Lim recovery is built for center=True (every SpeeChain preset)")
+        B, T, F = feat.shape
+        n_fft, hop, win = self.n_fft, self.hop_length, self.win_length
+        assert F == n_fft // 2 + 1 and n_fft % 2 == 0, (F, n_fft)
+        dev = feat.device
+        mag = feat.float().clamp_min(0.0)
+        mag = (mag if self.mag_spec else mag.sqrt()).reshape(B * T, F).contiguous()  # specgram.pow(1 / power)
+        L, M, nc = hop * (T - 1), B * T, 32 * lib.value("sc_frontend_num_tiles", n_fft)
+        basis = self._plan.basis(dev)
+        window, inv_basis = self._plan.synthesis(dev)
+        if _init_angles is not None:
+            a_re, a_im = _init_angles.real.float().reshape(M, F).contiguous(), _init_angles.imag.float().reshape(M, F).contiguous()
+        elif rand_init:
+            a = torch.rand(2, M, F, device=dev)
+            a_re, a_im = a[0], a[1]
+        else:
+            a_re, a_im = torch.ones(M, F, device=dev), torch.zeros(M, F, device=dev)
+        spec = torch.empty(M, nc, dtype=torch.float32, device=dev)
+        rebuilt, tprev = torch.empty_like(spec), torch.zeros_like(spec)
+        frames = torch.empty(M, n_fft, dtype=torch.float32, device=dev)
+        wav = torch.empty(B, L, dtype=torch.float32, device=dev)
+        full_len = torch.full((B,), L, dtype=torch.int64, device=dev)
+        coef = momentum / (1.0 + momentum)
+
+        def gemm(a, b, c, n, k):  # c (M, n) = a (M, k) x b (k, n), exact f32
+            lib.call("sc_gemm", 0, 0, 1, ptr(a), ptr(b), ptr(c), M, n, k, k, n, n, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 0.0,
+                     None, 0, 0, 0, stream())
+
+        def istft():
+            gemm(spec, inv_basis, frames, n_fft, nc)
+            lib.call("sc_istft_overlap_add", ptr(frames), ptr(window), win, n_fft, hop, B, T, ptr(wav), L, wav.stride(0), stream())
+
+        lib.call("sc_gl_phase_update", 0, ptr(mag), ptr(a_re), ptr(a_im), None, None, ptr(spec), M, n_fft, 0.0, stream())
+        for _ in range(n_iter):
+            istft()
+            lib.call("sc_frontend_frames", ptr(wav), ptr(full_len), B, L, wav.stride(0), 0, 0.0, n_fft, hop, 1, T, ptr(frames), stream())
+            gemm(frames, basis, rebuilt, nc, n_fft)
+            lib.call("sc_gl_phase_update", 1, ptr(mag), None, None, ptr(rebuilt), ptr(tprev), ptr(spec), M, n_fft, float(coef), stream())
+        istft()
+        return wav
 
     def get_sample_rate(self):
         return self.sr

@@ -715,6 +715,31 @@ def g11_decode():
     save("g11_decode", **out)
 
 
+# ---- G12 recover(): mel -> linear (reference, deterministic) and the post-processing around Griffin-Lim -----------------------------
+
+def g12_recover():
+    """LinearSpec2MelSpec.recover (linear2mel.py:191-224) as the reference computes it, and Speech2LinearSpec.recover
+    (speech2linear.py:252-351) with its ``griffin_lim`` member -- torchaudio.transforms.GriffinLim, absent here -- replaced by a function
+    that returns a fixed waveform: pins the length rule, the sliding-window inverse pre-emphasis and the silencing of the tails."""
+    from speechain.module.frontend.linear2mel import LinearSpec2MelSpec
+
+    g = torch.Generator().manual_seed(1212)
+    l2m = LinearSpec2MelSpec(n_fft=64, n_mels=12, sr=16000)
+    mel = torch.randn(3, 9, 12, generator=g) * 0.8 - 1.0
+    mel_len = torch.tensor([9, 6, 9])
+    lin = l2m.recover(mel.clone(), mel_len)
+    l2m_ln = LinearSpec2MelSpec(n_fft=64, n_mels=12, sr=16000, log_base=None)
+    lin_ln = l2m_ln.recover(mel.clone(), mel_len)
+    s2l = Speech2LinearSpec(hop_length=16, win_length=64, sr=16000, preemphasis=0.97)
+    T = 11
+    fixed = torch.randn(2, 16 * (T - 1), generator=g) * 0.1
+    s2l.griffin_lim = lambda spec: fixed.clone()
+    flen = torch.tensor([T, 7])
+    wav, wav_len = s2l.recover(torch.rand(2, T, 33, generator=g), flen, inv_preemph_winlen=20)
+    save("g12_recover", mel=mel, mel_len=mel_len, melw=l2m.mel_fbanks.weight, lin=lin, lin_ln=lin_ln, gl_wav=fixed, feat_len=flen, wav=wav,
+         wav_len=wav_len)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:

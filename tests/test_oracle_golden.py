@@ -369,3 +369,31 @@ def test_fastspeech2_oracle_matches_reference(golden):
 def test_average_scalar_by_duration_oracle(golden):
     g = golden("g10_tts")
     assert torch.allclose(R.average_scalar_by_duration(g["avg_frame"], g["avg_dur"]), g["avg_out"], atol=1e-6)
+
+
+def test_recover_oracle_matches_reference(golden):
+    """Row f4, recover(): the mel -> linear least-squares inversion and the post-processing around Griffin-Lim against the imported
+    reference (g12_recover; the iteration itself lives in the absent torchaudio and is restated from its published algorithm)."""
+    g = golden("g12_recover")
+    close(R.linear2mel_recover(g["mel"], g["mel_len"], g["melw"]), g["lin"], atol=1e-4, rtol=1e-3)
+    close(R.linear2mel_recover(g["mel"], g["mel_len"], g["melw"], log_base=None), g["lin_ln"], atol=1e-4, rtol=1e-3)
+    wav, wav_len = R.speech2linear_recover_post(g["gl_wav"], g["feat_len"], 16, 0.97, 20)
+    assert torch.equal(wav_len, g["wav_len"])
+    close(wav, g["wav"], atol=1e-6)
+
+
+def test_griffin_lim_oracle_reduces_the_spectral_error():
+    """The restated iteration (torchaudio's published algorithm) does what Griffin-Lim must: the magnitude spectrogram of its output
+    approaches the target with the iterations (a property; the third-party code itself cannot be run here)."""
+    gen = torch.Generator().manual_seed(2)
+    n_fft, hop = 64, 16
+    win = torch.hann_window(n_fft)
+    wave = torch.randn(2, 16 * 30, generator=gen).cumsum(-1) * 0.02
+    mag = torch.stft(wave, n_fft, hop, n_fft, win, return_complex=True).abs().transpose(1, 2)
+    init = torch.rand(2, mag.size(1), 33, generator=gen) + 1j * torch.rand(2, mag.size(1), 33, generator=gen)
+    errs = []
+    for n in (0, 4, 32):
+        y = R.griffin_lim(mag, win, n_fft, hop, n_fft, n, 0.99, init)
+        m2 = torch.stft(y, n_fft, hop, n_fft, win, return_complex=True).abs().transpose(1, 2)
+        errs.append(float((m2 - mag).norm() / mag.norm()))
+    assert errs[2] < errs[1] < errs[0] and errs[2] < 0.25, errs
