@@ -418,6 +418,7 @@ class ASRTrainStepWorkload:
         return {"bound": "mfma", "kernel": lib.load().sc_gemm_kernel_name(dom_id).decode(), "achieved": round(achieved, 2),
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5),
                 "traffic": pmc_traffic(lib.load().sc_gemm_kernel_name(dom_id).decode()),
+                "mfma_busy_pmc": pmc_mfma_busy(lib.load().sc_gemm_kernel_name(dom_id).decode()),
                 "launches_timed": dc, "avg_launch_ms": round(dt / max(dc, 1), 5), "kernel_flops_timed": df,
                 "all_gemm_launches": {"achieved": round(agg, 2), "frac": round(agg / MFMA_BF16_PEAK_TFLOPS, 5), "launches_timed": n,
                                       "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops},
@@ -428,7 +429,8 @@ class ASRTrainStepWorkload:
                         "2*M*N*K*batch flops / its event time; the split-K entries of by_kernel time two launches (product + "
                         "splitk_reduce_kernel) in one interval and are therefore not eligible as `kernel`; traffic: "
                         "HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_train_step_pmc_traffic.json: "
-                        "FETCH_SIZE x 2 + WRITE_SIZE over eager steps, averaged over the mix of shapes the kernel serves)"}
+                        "FETCH_SIZE x 2 + WRITE_SIZE over eager steps, averaged over the mix of shapes the kernel serves); mfma_busy_pmc: its matrix-core busy "
+                        "fraction from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (profiles/r02_train_step_pmc_mfma.json)"}
 
 
 # ---- BASELINE configs[4]: FastSpeech2 train step -----------------------------------------------------
@@ -713,6 +715,16 @@ def pmc_traffic(kernel: str):
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+def pmc_mfma_busy(kernel: str):
+    """Matrix-core busy fraction of `kernel` from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (None when there is none)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_train_step_pmc_mfma.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["mfma_busy_frac"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):

@@ -65,6 +65,29 @@ def main():
                     "dispatch is counted), averaged over every launch of the kernel in the run -- i.e. over the MIX of shapes a kernel serves in the step; FETCH_SIZE "
                     "doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3); unit 1000 B")
     json.dump(tr, open(f"{P}{tag}_train_step_pmc_traffic.json", "w"), indent=1)
+    # matrix-core busy fraction per kernel from the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass: the counter sums busy cycles over the
+    # 1024 SIMDs of the chip (32 per v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md), GRBM_GUI_ACTIVE the active cycles of the 8 XCDs
+    try:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(newest(G + "train_mfma/*/*counter_collection.csv"))):
+            for key in TRAIN_KERNELS:
+                if key in r["Kernel_Name"]:
+                    agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        mf = {}
+        for k, c in agg.items():
+            busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", []), c.get("GRBM_GUI_ACTIVE", [])
+            if busy and act:
+                mf[k] = dict(launches_counted=len(busy), mfma_busy_cycles_per_launch=round(sum(busy) / len(busy)),
+                             gui_active_cycles_per_launch=round(sum(act) / len(act)),
+                             mfma_busy_frac=round(sum(busy) / (128.0 * sum(act)), 4))
+        mf["_note"] = ("`--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass of `BENCH_NO_GRAPH=1 BENCH_NO_PREFETCH=1 python bench.py --steps 3 --warmup 2`; "
+                       "mfma_busy_frac = busy cycles summed over the chip's 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE / 8), averaged over the launches of a kernel")
+        json.dump(mf, open(f"{P}{tag}_train_step_pmc_mfma.json", "w"), indent=1)
+        for k in TRAIN_KERNELS:
+            if k in mf:
+                print(f"  mfma busy {k}: {mf[k]['mfma_busy_frac']:.3f} over {mf[k]['launches_counted']} launches")
+    except (ValueError, OSError) as e:
+        print("no MFMA pass:", e)
     for name in ("train_step_bench_default", "train_step_bench_prenet512", "train_step_bench_under_rocprof", "tts_step_bench_default", "tts_step_bench_under_rocprof"):
         d = json.load(open(f"{P}{tag}_{name}.json"))
         r = d["roofline"]

@@ -14,7 +14,7 @@ python3 bench.py --workload tts_train_step > $O/bench_tts.json 2> $O/bench_tts.e
 python3 bench.py --workload asr_decode --steps 20 --warmup 3 > $O/bench_decode.json 2> $O/bench_decode.err
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel statistics"
-rm -rf $O/train $O/frontend $O/tts $O/decode $O/train_fetch $O/train_write $O/frontend_fetch $O/frontend_write
+rm -rf $O/train $O/frontend $O/tts $O/decode $O/train_mfma $O/train_fetch $O/train_write $O/frontend_fetch $O/frontend_write
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 $R/bench.py --steps 20 --warmup 6 --no-cpu-baseline > $O/train_bench.json 2> $O/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/frontend -- python3 $R/bench.py --workload frontend --steps 30 --warmup 5 --no-cpu-baseline > $O/frontend_bench.json 2> $O/frontend.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tts -- python3 $R/bench.py --workload tts_train_step --steps 20 --warmup 6 --no-cpu-baseline > $O/tts_bench.json 2> $O/tts.err
@@ -23,6 +23,7 @@ echo "== counters"
 export BENCH_NO_GRAPH=1 BENCH_NO_PREFETCH=1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/train_fetch -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/train_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/train_write -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/train_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/train_mfma -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/train_mfma.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/frontend_fetch -- python3 $R/bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/frontend_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/frontend_write -- python3 $R/bench.py --workload frontend --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/frontend_write.err
 ls $O
