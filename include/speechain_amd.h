@@ -304,7 +304,11 @@ int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
                      void* dK, void* dV, int B, int H, int Tq, int Tk, long long q_b, long long ldq, long long kv_b,
                      long long ldk, long long o_b, long long ldo, long long dq_b, long long lddq, long long dkv_b, long long lddk,
                      const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale, float drop_p,
-                     const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
+                     const unsigned long long* seed, unsigned long long offset, float* dq_workspace, long long ws_bytes,
+                     hipStream_t stream);
+/* bytes of the f32 workspace sc_attention_bwd needs for Tk keys: 0 up to 256 keys; beyond, the keys are swept in blocks of 256, one launch
+ * each, and dQ is summed through (B H, Tq, 64) floats in launch order (dq_workspace may be NULL otherwise). */
+long long sc_attention_bwd_workspace(int B, int H, int Tq, int Tk);
 
 /* ---- cached-key/value decoding (csrc/decode.hip): the inference callers of SURVEY.md row f3 --------------------------------
  * Replaces, inside speechain/infer_func/beam_search.py:325-333 + :518-521, the re-run of the whole decoder on the whole prefix at

@@ -28,7 +28,7 @@ lib.call("sc_attention_fwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(lse
 for _ in range(3):
     lib.call("sc_attention_bwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(do), Fn._p(lse), Fn._p(dq), Fn._p(dk), Fn._p(dv), B, H,
              Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1),
-             dk.stride(0), dk.stride(1), None, 0, 0, 0, scale, drop_p, Fn._p(seed), 0, stream())
+             dk.stride(0), dk.stride(1), None, 0, 0, 0, scale, drop_p, Fn._p(seed), 0, None, 0, stream())
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 512)()
 fn = lib.load().sc_attention_debug_read

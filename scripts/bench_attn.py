@@ -36,7 +36,7 @@ def run(name, Tq, Tk, causal, drop_p, B=32, H=8, dh=64, iters=50):
     def bwd():
         lib.call("sc_attention_bwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(do), Fn._p(lse), Fn._p(dq), Fn._p(dk), Fn._p(dv), B, H,
                  Tq, Tk, q.stride(0), q.stride(1), k.stride(0), k.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1),
-                 dk.stride(0), dk.stride(1), Fn._p(m8), m8.stride(0), 0, causal, scale, drop_p, Fn._p(seed), 0, stream())
+                 dk.stride(0), dk.stride(1), Fn._p(m8), m8.stride(0), 0, causal, scale, drop_p, Fn._p(seed), 0, None, 0, stream())
 
     res = []
     for fn in (fwd, bwd):

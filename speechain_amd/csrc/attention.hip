@@ -44,6 +44,10 @@ struct AttnArgs {
   unsigned short* dK;
   unsigned short* dV;
   long long dq_b, lddq, dkv_b, lddk;
+  // key-block sweep of the key-on-the-lane backward (more than 256 keys): this launch owns keys [key0, key0 + 32 NW)
+  int key0;
+  int dq_mode;   // 0: dQ final (bf16); 1: f32 partial -> dq_ws; 2: dq_ws + partial -> bf16 final; 3: dq_ws += partial
+  float* dq_ws;  // (B H, Tq, 64) f32
 };
 
 // k-contiguous MFMA 32x32x16 operand fragment: row `row`, elements k0 + 8*(lane>>5) .. +7 of a [rows][ld] bf16 tile
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
   const unsigned short* dOg = p.dO + b * p.o_b + hd * DH;
   const unsigned short* Ogh = Og + b * p.o_b + hd * DH;
   const int wkey0 = wid * 32;
-  const bool wave_on = wkey0 < p.Tk;  // a wave without keys only takes part in the dQ product
+  const bool wave_on = p.key0 + wkey0 < p.Tk;  // a wave without keys only takes part in the dQ product
   KL_PROBE(7, 0);
   const float inv_scale = 1.f / p.scale, c1 = p.scale * 1.4426950408889634f, unkeep = 1.f - p.drop_p;
 
@@ -726,10 +730,11 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
   for (int i = 0; i < KPT; ++i) {
     const int c = tid + i * NT, r = c >> 3, ch = c & 7;
     kreg[i] = make_uint4(0, 0, 0, 0);
-    if (r < p.Tk) kreg[i] = *(const uint4*)(Kg + (long long)r * p.ldk + ch * 8);
+    if (p.key0 + r < p.Tk) kreg[i] = *(const uint4*)(Kg + (long long)(p.key0 + r) * p.ldk + ch * 8);
   }
   bf16x8_t kf[4], vf[4];
-  const int key = wkey0 + li;
+  const int key = p.key0 + wkey0 + li;  // (absolute; the LDS images are indexed by the key inside this launch's block, lkey)
+  const int lkey = wkey0 + li;
   const int kc = min(key, p.Tk - 1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8_t*)(Vg + (long long)kc * p.ldk + ks * 16 + h * 8);
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   KL_BARRIER();  // K image, stage 0
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_rowmajor(Kimg, LDR, key, ks * 16, lane);
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_rowmajor(Kimg, LDR, lkey, ks * 16, lane);
 
   const int g = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
   const int ud = wid & 1, uq = (wid >> 1) & 1, ukh = wid >> 2;  // dQ unit of this wave: head-dim block, query block, key half
@@ -774,12 +779,28 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
     const int q = q0 + uq * 32 + li;
     if (q < p.Tq) {
       const float f = p.scale * p.drop_keep;
-      unsigned short* dQg = p.dQ + b * p.dq_b + hd * DH + (long long)q * p.lddq + ud * 32 + 4 * h;
+      float v[16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned w0 = sc_f32_to_bf16(acc[4 * j] * f) | ((unsigned)sc_f32_to_bf16(acc[4 * j + 1] * f) << 16);
-        const unsigned w1 = sc_f32_to_bf16(acc[4 * j + 2] * f) | ((unsigned)sc_f32_to_bf16(acc[4 * j + 3] * f) << 16);
-        *(uint2*)(dQg + 8 * j) = make_uint2(w0, w1);
+      for (int r = 0; r < 16; ++r) v[r] = acc[r] * f;
+      float* ws = p.dq_ws + ((long long)z * p.Tq + q) * DH + ud * 32 + 4 * h;  // (only touched in modes 1-3)
+      if (p.dq_mode >= 2) {  // this launch continues the sum of the earlier key blocks
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = *(const float4*)(ws + 8 * j);
+          v[4 * j] += t.x; v[4 * j + 1] += t.y; v[4 * j + 2] += t.z; v[4 * j + 3] += t.w;
+        }
+      }
+      if (p.dq_mode == 1 || p.dq_mode == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4*)(ws + 8 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+      } else {
+        unsigned short* dQg = p.dQ + b * p.dq_b + hd * DH + (long long)q * p.lddq + ud * 32 + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned w0 = sc_f32_to_bf16(v[4 * j]) | ((unsigned)sc_f32_to_bf16(v[4 * j + 1]) << 16);
+          const unsigned w1 = sc_f32_to_bf16(v[4 * j + 2]) | ((unsigned)sc_f32_to_bf16(v[4 * j + 3]) << 16);
+          *(uint2*)(dQg + 8 * j) = make_uint2(w0, w1);
+        }
       }
     }
   };
@@ -892,7 +913,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const uint4 w = __builtin_bit_cast(uint4, dsf[ss]);
-          unsigned short* trow = Timg + key * LDR + qb * 32 + 16 * ss + 4 * h;
+          unsigned short* trow = Timg + lkey * LDR + qb * 32 + 16 * ss + 4 * h;
           *(uint2*)(trow) = make_uint2(w.x, w.y);
           *(uint2*)(trow + 8) = make_uint2(w.z, w.w);
         }
@@ -957,7 +978,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kl_kernel(AttnArgs p, con
       unsigned short* dst = (m == 0 ? p.dK : p.dV) + b * p.dkv_b + hd * DH;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = 8 * i + (lane >> 3), kk = wkey0 + r;
+        const int r = 8 * i + (lane >> 3), kk = p.key0 + wkey0 + r;
         const uint4 v = *(const uint4*)(stg + r * LDR + (lane & 7) * 8);
         if (kk < p.Tk) *(uint4*)(dst + (long long)kk * p.lddk + (lane & 7) * 8) = v;
       }
@@ -1006,13 +1027,19 @@ SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O
   return SC_OK;
 }
 
+// bytes of the f32 dQ workspace sc_attention_bwd needs (0 up to 256 keys)
+SC_API long long sc_attention_bwd_workspace(int B, int H, int Tq, int Tk) {
+  return Tk <= TKMAX ? 0 : (long long)B * H * Tq * DH * (long long)sizeof(float);
+}
+
 SC_API int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ,
                             void* dK, void* dV, int B, int H, int Tq, int Tk, long long q_b, long long ldq, long long kv_b,
                             long long ldk, long long o_b, long long ldo, long long dq_b, long long lddq, long long dkv_b,
                             long long lddk, const unsigned char* mask, long long mask_b, long long mask_q, int causal, float scale,
-                            float drop_p, const unsigned long long* seed, unsigned long long offset, hipStream_t stream) {
+                            float drop_p, const unsigned long long* seed, unsigned long long offset, float* dq_workspace,
+                            long long ws_bytes, hipStream_t stream) {
   SC_CHECK_ARG(Q && K && V && O && dO && LSE && dQ && dK && dV, "sc_attention_bwd: null pointer");
-  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1 && Tk <= TKMAX, "sc_attention_bwd: need 1 <= Tk <= %d (got %d)", TKMAX, Tk);
+  SC_CHECK_ARG(B >= 1 && H >= 1 && Tq >= 1 && Tk >= 1, "sc_attention_bwd: bad sizes");
   SC_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0 && q_b % 8 == 0 && kv_b % 8 == 0 && o_b % 8 == 0 &&
                    (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 && (uintptr_t)V % 16 == 0 && (uintptr_t)O % 16 == 0 &&
                    (uintptr_t)dO % 16 == 0, "sc_attention_bwd: operands must be 16-byte aligned with strides multiple of 8");
@@ -1029,17 +1056,28 @@ SC_API int sc_attention_bwd(const void* Q, const void* K, const void* V, const v
   const bool kl_ok = lddq % 4 == 0 && dq_b % 4 == 0 && lddk % 8 == 0 && dkv_b % 8 == 0 && (uintptr_t)dQ % 8 == 0 && (uintptr_t)dK % 16 == 0 &&
                      (uintptr_t)dV % 16 == 0 && getenv("SC_ATTN_BWD_OLD") == nullptr;
   if (kl_ok) {
-    const int nw = Tk > 128 ? 8 : 4;
-    const size_t smem = (size_t)(2 * 32 * nw + 4 * 64) * LDR * 2 + 4 * 64 * sizeof(float) + (nw == 8 ? 4 * 4 * 64 * 4 * sizeof(float) : 0);
-    const void* fn = nw == 8 ? (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<8, true> : (const void*)attn_bwd_kl_kernel<8, false>)
-                             : (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<4, true> : (const void*)attn_bwd_kl_kernel<4, false>);
-    SC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    // 256 keys per launch; more keys: one launch per key block, each sweeping all queries, dQ summed through the caller's f32 workspace
+    // in launch order (deterministic: the same workgroup adds a (batch, head)'s blocks one after the other)
+    const int nblk = sc_cdiv(Tk, TKMAX);
+    SC_CHECK_ARG(nblk == 1 || (dq_workspace && ws_bytes >= sc_attention_bwd_workspace(B, H, Tq, Tk)),
+                 "sc_attention_bwd: %d keys need a dQ workspace of %lld bytes (sc_attention_bwd_workspace)", Tk, sc_attention_bwd_workspace(B, H, Tq, Tk));
     const unsigned short* Oc = (const unsigned short*)O;
-    void* kargs[] = {&a, &Oc};
-    SC_HIP(hipLaunchKernel(fn, dim3(B * H), dim3(64 * nw), kargs, smem, stream));
-    SC_LAUNCH_CHECK("attn_bwd_kl_kernel");
+    for (int blk = 0; blk < nblk; ++blk) {
+      a.key0 = blk * TKMAX;
+      a.dq_mode = nblk == 1 ? 0 : (blk == 0 ? 1 : (blk == nblk - 1 ? 2 : 3));
+      a.dq_ws = dq_workspace;
+      const int nw = (Tk - a.key0) > 128 ? 8 : 4;
+      const size_t smem = (size_t)(2 * 32 * nw + 4 * 64) * LDR * 2 + 4 * 64 * sizeof(float) + (nw == 8 ? 4 * 4 * 64 * 4 * sizeof(float) : 0);
+      const void* fn = nw == 8 ? (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<8, true> : (const void*)attn_bwd_kl_kernel<8, false>)
+                               : (drop_p > 0.f ? (const void*)attn_bwd_kl_kernel<4, true> : (const void*)attn_bwd_kl_kernel<4, false>);
+      SC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      void* kargs[] = {&a, &Oc};
+      SC_HIP(hipLaunchKernel(fn, dim3(B * H), dim3(64 * nw), kargs, smem, stream));
+      SC_LAUNCH_CHECK("attn_bwd_kl_kernel");
+    }
     return SC_OK;
   }
+  SC_CHECK_ARG(Tk <= TKMAX, "sc_attention_bwd: the previous kernel holds at most %d keys (got %d)", TKMAX, Tk);
   const size_t smem = (size_t)(2 * 64 + 2 * TKMAX) * LDR * 2 + (size_t)2 * 64 * LDPB * 2 + 2 * 64 * sizeof(float);
   SC_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(512), smem, stream, a, (const unsigned short*)O);

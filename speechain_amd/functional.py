@@ -1050,10 +1050,12 @@ class _AttnFused(torch.autograd.Function):
         if mq == 0:  # fused backward: probabilities are recomputed on chip from Q, K and the saved logsumexp
             dq_buf = torch.empty_like(q_buf)
             dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
+            ws_bytes = lib.value("sc_attention_bwd_workspace", B, H, Tq, Tk)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev) if ws_bytes else None
             lib.call("sc_attention_bwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(dout), _p(lse),
                      _p(dq_buf, iq * d), _p(dkv_buf, ik * d), _p(dkv_buf, iv * d), B, H, Tq, Tk, sqb, ldq, skb, ldk, out.stride(0),
                      out.stride(1), dq_buf.stride(0), dq_buf.stride(1), dkv_buf.stride(0), dkv_buf.stride(1), _p(m8), mb, mq,
-                     1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
+                     1 if causal else 0, float(scale), float(drop_p), seed, off, _p(ws), ws_bytes, stream())
             return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
         # dense (B, Tq, Tk) mask: recompute P (and its dropped copy) exactly as the unfused forward does
         S = torch.empty(Z, Tq, ld, dtype=dt, device=dev)
@@ -1084,8 +1086,10 @@ class _AttnFused(torch.autograd.Function):
 def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, scale, drop_p):
     same = kv_buf is None or kv_buf is q_buf
     Tk = (q_buf if same else kv_buf).size(1)
-    # (the fused backward kernel holds the keys of a head in LDS: at most 256; the streaming forward takes any number)
-    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and (Tk <= 256 or not torch.is_grad_enabled())
+    # (any number of keys: the streaming forward tiles them, the backward sweeps them in blocks of 256.  A query-dependent mask -- only
+    #  Conformer-style subclasses pass one -- takes the forward kernel that holds a head's keys in LDS: at most 256)
+    dense_mask = mask is not None and mask.dim() == 3 and mask.size(1) > 1
+    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and (Tk <= 256 or not dense_mask)
             and q_buf.stride(1) % 8 == 0 and (same or kv_buf.stride(1) % 8 == 0)):
         out = _AttnFused.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
                                float(drop_p))

@@ -414,7 +414,7 @@ def test_batched_weight_refresh_matches_lazy_casts():
 
 
 @pytest.mark.parametrize("drop_p", [0.0, 0.2])
-@pytest.mark.parametrize("case", ["self_pad", "self_causal", "cross"])
+@pytest.mark.parametrize("case", ["self_pad", "self_causal", "cross", "self_long"])
 def test_fused_attention_matches_unfused(case, drop_p):
     """bf16, head size 64: the fused kernel (no score tensor in HBM) against the GEMM + softmax + GEMM path, forward and
     gradients, with padding mask, causal flag and dropout (identical masks by construction)."""
@@ -425,6 +425,8 @@ def test_fused_attention_matches_unfused(case, drop_p):
         torch.manual_seed(5)
         d, H, B = 256, 4, 3
         Tq, Tk = (249, 249) if case != "cross" else (63, 249)
+        if case == "self_long":  # a 15 s utterance: 375 frames, two key blocks in the backward sweep
+            Tq = Tk = 375
         m = MultiHeadedAttention(num_heads=H, d_model=d, dropout=drop_p).cuda().train()
         q = torch.randn(B, Tq, d, device="cuda", requires_grad=True)
         kv = q if case != "cross" else torch.randn(B, Tk, d, device="cuda", requires_grad=True)
@@ -485,9 +487,10 @@ def test_streaming_attention_forward_through_the_c_abi(Tq, Tk, causal):
 
 
 @pytest.mark.parametrize("Tq,Tk,causal", [(249, 249, False), (63, 249, False), (63, 63, True), (130, 130, True), (1, 5, False), (300, 64, False),
-                                          (70, 128, False), (200, 129, False), (64, 256, False), (33, 200, False)])
+                                          (70, 128, False), (200, 129, False), (64, 256, False), (33, 200, False),
+                                          (300, 300, False), (375, 375, True), (70, 600, False), (500, 257, False)])
 def test_attention_backward_through_the_c_abi(Tq, Tk, causal):
-    """sc_attention_bwd (key-on-the-lane kernel; 32 or 64 keys per wave by Tk) on packed (B, T, H*64) bf16 buffers against torch
+    """sc_attention_bwd (key-on-the-lane kernel; 4 or 8 waves of 32 keys per launch, one launch per block of 256 keys) on packed (B, T, H*64) bf16 buffers against torch
     autograd in fp32 on the same bf16 values: dQ, dK, dV (bf16 outputs of sums over bf16-rounded P and dS: 2 % of the largest
     element); ragged key masks, an utterance without visible keys (zero gradients), query counts that are not multiples of 64."""
     from speechain_amd._lib import lib, stream
@@ -506,9 +509,12 @@ def test_attention_backward_through_the_c_abi(Tq, Tk, causal):
     lib.call("sc_attention_fwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(lse), B, H, Tq, Tk, q.stride(0), q.stride(1), k.stride(0),
              k.stride(1), out.stride(0), out.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, stream())
     dq, dk, dv = (torch.full_like(t, float("nan")) for t in (q, k, v))
+    ws_bytes = lib.value("sc_attention_bwd_workspace", B, H, Tq, Tk)  # more than 256 keys: dQ is summed over the key blocks through it
+    assert (ws_bytes > 0) == (Tk > 256)
+    ws = torch.full((max(ws_bytes // 4, 1),), float("nan"), device="cuda")
     lib.call("sc_attention_bwd", Fn._p(q), Fn._p(k), Fn._p(v), Fn._p(out), Fn._p(do), Fn._p(lse), Fn._p(dq), Fn._p(dk), Fn._p(dv), B, H, Tq, Tk,
              q.stride(0), q.stride(1), k.stride(0), k.stride(1), out.stride(0), out.stride(1), dq.stride(0), dq.stride(1), dk.stride(0),
-             dk.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, stream())
+             dk.stride(1), Fn._p(m8), m8.stride(0), 0, 1 if causal else 0, scale, 0.0, None, 0, Fn._p(ws) if ws_bytes else None, ws_bytes, stream())
     qf, kf, vf = (t.float().view(B, -1, H, dh).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
     s_ = (qf @ kf.transpose(-1, -2)) * scale
     ok = m8.bool()[:, :, None, :].expand(B, H, Tq, Tk).clone()
