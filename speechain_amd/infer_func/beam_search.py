@@ -184,7 +184,12 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
     N, V = B * beam_size, vocab_size
     cached = hasattr(asr_decode_fn, "start_decoding") and hasattr(asr_decode_fn, "forward_step")
     use_lm = lm_decode_fn is not None and lm_weight > 0
-
+    if cached and not use_lm and feat_maxlen % 32 != 0:
+        # the replayed session is keyed by its geometry: pad the frames to a multiple of 32 (masked out everywhere: cross-attention by the
+        # mask, the CTC scorer by the lengths) so that utterances of nearby lengths share one session and its hipGraphs
+        extra = 32 - feat_maxlen % 32
+        enc_feat = torch.nn.functional.pad(enc_feat, (0, 0, 0, extra))
+        enc_feat_mask = torch.cat([enc_feat_mask, torch.zeros(B, enc_feat_mask.size(1), extra, dtype=enc_feat_mask.dtype, device=dev)], dim=-1)
     # ---- CTC scorer: one copy of the log-probabilities per sentence ----
     ctc_scorer, ctc_memory = None, None
     if ctc_decode_fn is not None and ctc_weight > 0:
@@ -198,9 +203,10 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
     session = None
     if cached and not use_lm:
         w = float(ctc_weight) if ctc_scorer is not None else 0.0
-        key = (B, beam_size, V, feat_maxlen, max(hypo_maxlen, 1), str(enc_feat.dtype), str(dev), w, float(temperature), padding_idx, sos_eos,
+        frames, cache_len = enc_feat.size(1), (max(hypo_maxlen, 1) + 15) // 16 * 16  # (padded frames; cache positions in steps of 16)
+        key = (B, beam_size, V, frames, cache_len, str(enc_feat.dtype), str(dev), w, float(temperature), padding_idx, sos_eos,
                bool(eos_filtering), str(Fn.compute_dtype()))
-        session = _session_for(asr_decode_fn, key, B, beam_size, V, feat_maxlen, max(hypo_maxlen, 1), dev, w, float(temperature), padding_idx,
+        session = _session_for(asr_decode_fn, key, B, beam_size, V, frames, cache_len, dev, w, float(temperature), padding_idx,
                                sos_eos, bool(eos_filtering))
         session.begin(enc_feat, enc_feat_mask, ctc_scorer)
     if session is None:  # (with a language model in the loop the decoder is called the reference's way as well)
