@@ -491,9 +491,10 @@ def ctc_nll_explicit(log_probs: Tensor, target: Sequence[int], blank: int = 0) -
 
 
 def cross_entropy(logits: Tensor, text: Tensor, text_len: Tensor, label_smoothing: float = 0.0,
-                  length_normalized: bool = False, temperature: float = 1.0) -> Tensor:
-    """Label-smoothed, length-masked CE (confid_threshold=0, no token weights).  When ``text`` carries a
-    leading <sos/eos> (one longer than logits) it is dropped and lengths shrink by one (:115-125)."""
+                  length_normalized: bool = False, temperature: float = 1.0, token_weights: Optional[Tensor] = None,
+                  confid_threshold: float = 0.0, confid_level: str = "sentence") -> Tensor:
+    """Label-smoothed, length-masked CE with the optional token re-weighting (:148-149) and confidence thresholding (:160-199).  When
+    ``text`` carries a leading <sos/eos> (one longer than logits) it is dropped and lengths shrink by one (:115-125)."""
     if logits.size(1) == text.size(1) - 1:
         text, text_len = text[:, 1:], text_len - 1
     B, L, V = logits.shape
@@ -503,11 +504,26 @@ def cross_entropy(logits: Tensor, text: Tensor, text_len: Tensor, label_smoothin
         tok = lp_t * (1 - label_smoothing) + (lp * (label_smoothing / V)).sum(dim=1)
     else:
         tok = lp_t
-    valid = make_mask_from_len(text_len, max_len=L, return_3d=False).reshape(-1)
-    sent = tok.masked_fill(~valid, 0.0).reshape(B, L).sum(dim=-1)
+    if token_weights is not None:
+        tok = tok * token_weights[text.reshape(-1)]
+    valid = make_mask_from_len(text_len, max_len=L, return_3d=False)
+    drop = ~valid.reshape(-1)
+    valid_sent = None
+    if confid_threshold > 0:
+        if confid_level == "token":  # tokens the model is not confident about leave the loss and the sentence lengths (:161-170)
+            low = lp_t <= math.log(confid_threshold)
+            drop = drop | low
+            text_len = (~low.reshape(B, L)).masked_fill(~valid, False).sum(dim=-1)
+            valid_sent = text_len > 0
+        else:  # whole sentences whose summed log-probability is below len * log(threshold) (:171-184)
+            sent_lp = lp_t.reshape(B, L).masked_fill(~valid, 0.0).sum(dim=-1, keepdim=True)
+            low = sent_lp <= (text_len * math.log(confid_threshold)).unsqueeze(-1)
+            drop = drop | low.expand(-1, L).reshape(-1)
+            valid_sent = ~low.squeeze(-1)
+    sent = tok.masked_fill(drop, 0.0).reshape(B, L).sum(dim=-1)
     if length_normalized:
         sent = sent / (text_len + 1e-10)
-    return -sent.mean()
+    return -sent.mean() if confid_threshold == 0 else -sent.sum() / (valid_sent.sum() + 1e-10)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -740,6 +740,34 @@ def g12_recover():
          wav_len=wav_len)
 
 
+# ---- G13 CrossEntropy options: token re-weighting and confidence thresholding (cross_entropy.py:81-95,148-199) ----------------------
+
+def g13_ce_options():
+    out = {}
+    g = torch.Generator().manual_seed(1313)
+    V = 29
+    logits = (torch.randn(4, 7, V, generator=g) * 1.5).requires_grad_(True)
+    text = torch.randint(1, V - 2, (4, 8), generator=g)
+    text_len = torch.tensor([8, 6, 8, 3])
+    for i, l in enumerate(text_len):
+        text[i, 0] = V - 1
+        text[i, l - 1] = V - 1
+        text[i, l:] = 0
+    weights = torch.ones(V)
+    weights[3], weights[11], weights[V - 1] = 2.5, 0.25, 0.0
+    out.update(logits=logits, text=text, text_len=text_len, weights=weights)
+    cases = dict(w=dict(label_smoothing=0.1), tok=dict(confid_threshold=0.05, confid_level="token", length_normalized=True),
+                 sent=dict(confid_threshold=0.02, confid_level="sentence"), tok_ls=dict(confid_threshold=0.08, confid_level="token", label_smoothing=0.2))
+    for tag, conf in cases.items():
+        crit = CrossEntropy(**conf)
+        if tag == "w":
+            crit.token_weights = weights  # (criterion_init builds it from a vocabulary file and .cuda(): cross_entropy.py:85-95)
+        loss = crit(logits=logits, text=text.clone(), text_len=text_len.clone())
+        (gl,) = torch.autograd.grad(loss, logits)
+        out.update({f"{tag}.loss": loss, f"{tag}.grad": gl})
+    save("g13_ce_options", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:

@@ -397,3 +397,15 @@ def test_griffin_lim_oracle_reduces_the_spectral_error():
         m2 = torch.stft(y, n_fft, hop, n_fft, win, return_complex=True).abs().transpose(1, 2)
         errs.append(float((m2 - mag).norm() / mag.norm()))
     assert errs[2] < errs[1] < errs[0] and errs[2] < 0.25, errs
+
+
+def test_cross_entropy_options_oracle(golden):
+    """Token re-weighting and confidence thresholding of the oracle's cross entropy against the imported reference (g13_ce_options)."""
+    g = golden("g13_ce_options")
+    cases = dict(w=dict(label_smoothing=0.1, token_weights=g["weights"]), tok=dict(confid_threshold=0.05, confid_level="token", length_normalized=True),
+                 sent=dict(confid_threshold=0.02, confid_level="sentence"), tok_ls=dict(confid_threshold=0.08, confid_level="token", label_smoothing=0.2))
+    for tag, conf in cases.items():
+        lg = g["logits"].clone().requires_grad_()
+        loss = R.cross_entropy(lg, g["text"], g["text_len"], **conf)
+        close(loss.detach(), g[f"{tag}.loss"], atol=1e-5)
+        close(torch.autograd.grad(loss, lg)[0], g[f"{tag}.grad"], atol=1e-6, rtol=1e-4)

@@ -211,6 +211,28 @@ def test_losses(golden, mode):
     close(torch.autograd.grad(loss, lg)[0], g["ctc_grad"], gt, "ctc grad")
 
 
+def test_cross_entropy_options(golden, mode, tmp_path):
+    """Token re-weighting and confidence thresholding (cross_entropy.py:81-95,148-199) against the imported reference (g13_ce_options):
+    losses and gradients; the weights also through the vocabulary-file constructor path."""
+    from speechain_amd.criterion.cross_entropy import CrossEntropy
+
+    g = golden("g13_ce_options")
+    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(atol=5e-2, rtol=2e-2)
+    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(atol=3e-3, rtol=5e-2)
+    vocab = tmp_path / "vocab"
+    vocab.write_text("\n".join(f"tok{i}" for i in range(29)) + "\n")
+    cases = dict(w=dict(label_smoothing=0.1, token_vocab=str(vocab), new_weights={"tok3": 2.5, "tok11": 0.25, "tok28": 0.0}),
+                 tok=dict(confid_threshold=0.05, confid_level="token", length_normalized=True),
+                 sent=dict(confid_threshold=0.02, confid_level="sentence"),
+                 tok_ls=dict(confid_threshold=0.08, confid_level="token", label_smoothing=0.2))
+    for tag, conf in cases.items():
+        lg = g["logits"].to(mode).cuda().requires_grad_()
+        loss = CrossEntropy(**conf)(logits=lg, text=g["text"].cuda(), text_len=g["text_len"].cuda())
+        if mode == torch.float32 or tag == "w":  # (bf16 logits can move a token across a confidence threshold: compared in f32 only)
+            close(loss, g[f"{tag}.loss"], lt, tag)
+            close(torch.autograd.grad(loss, lg)[0], g[f"{tag}.grad"], gt, tag + " grad")
+
+
 def test_ctc_edge_cases_vs_oracle():
     """Infeasible alignment (more labels + forced blanks than frames: zero_infinity path), an utterance shorter than the
     padded batch (zero gradient beyond its length), a label repeated three times, a single-label target."""
