@@ -1258,8 +1258,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
 template <int WM, int WN, int MI, int PF, bool KTAIL = false>
 int launch_dma_pf(const GemmArgs& a, int nbatch, hipStream_t stream) {
   constexpr int TM = WM * MI * 32, TN = WN * 64;
-  constexpr size_t smem = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short);
-  static_assert(smem >= (size_t)WM * WN * 32 * STG_LD * sizeof(float), "operand stages must cover the epilogue staging");
+  constexpr size_t smem_ring = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short), smem_stg = (size_t)WM * WN * 32 * STG_LD * sizeof(float);
+  constexpr size_t smem = smem_ring > smem_stg ? smem_ring : smem_stg;  // (the operand stages double as the epilogue staging)
   auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF, KTAIL>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1466,6 +1466,7 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_nt_dma_kernel<2, 1, 1, 1, false>",
     "wgrad_grouped_kernel<2, 4, 4>",
     "wgrad_grouped_kernel<2, 2, 2>",
+    "gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 SC_API const char* sc_gemm_kernel_name(int id) {
@@ -1528,7 +1529,21 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // SC_GEMM_T64=<max tiles> overrides (0 switches the variant off).
       static const long long t64max = [] { const char* e = getenv("SC_GEMM_T64"); return e ? atoll(e) : 80LL; }();
       if (t128 <= t64max) { g_last_gemm_kernel = 12; return launch_dma<2, 1, 1, 1>(a, nb, stream); }
-      if (t128 <= 192) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1, 2>(a, nb, stream); }
+      static const long long t64x128max = [] { const char* e = getenv("SC_GEMM_T64X128"); return e ? atoll(e) : 192LL; }();
+      if (t128 <= t64x128max) { g_last_gemm_kernel = 11; return launch_dma<2, 2, 1, 2>(a, nb, stream); }
+      // At most one 128 x 128 tile per CU (M = 7968, N = 512: 252 tiles): the tile runs on 8 waves of 32 x 64 -- two per SIMD, so one wave's
+      // fragment reads and address arithmetic overlap the other's matrix-core work -- instead of 4 waves of 64 x 64.  Kernel A/B (one box):
+      // K = 512 10.5 -> 9.9 us, K = 1024 15.2 -> 14.4, K = 2048 25.5 -> 25.2, K = 96 7.1 -> 6.4, K = 2048 + bias + residual 28.1 -> 26.0;
+      // step A/B (alternating, 60 steps): 9.17 / 9.17 ms without, 8.94 / 9.01 ms with.  SC_GEMM_W8=0 switches it off, SC_GEMM_W8_MAX=<tiles>
+      // moves the threshold.
+      static const int w8 = [] { const char* e = getenv("SC_GEMM_W8"); return e ? atoi(e) : 3; }();
+      static const long long w8max = [] { const char* e = getenv("SC_GEMM_W8_MAX"); return e ? atoll(e) : (1LL << 60); }();
+      if (w8 && t128 <= w8max && a.K % BK16 == 0) {
+        g_last_gemm_kernel = 15;
+        if (w8 == 1) return launch_dma_pf<4, 2, 1, 0>(a, nb, stream);
+        if (w8 == 2) return launch_dma_pf<4, 2, 1, 1>(a, nb, stream);
+        return launch_dma_pf<4, 2, 1, 2>(a, nb, stream);
+      }
       g_last_gemm_kernel = 1;
       return launch_dma<2, 2, 2, 2>(a, nb, stream);
     }
