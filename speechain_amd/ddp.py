@@ -129,6 +129,17 @@ class GradBucketReducer:
             # event.  The caller reduces every bucket eagerly after the replay instead (reduce_all_now).
             return
         if self.cuda:
+            from speechain_amd.functional import _Side
+
+            # Gradients of a forward branch (harness: the CTC head) are written on a stream of their own, and the hook that completes a
+            # bucket may fire on either: the stream the bucket leaves from waits for the step's main stream and every side stream.
+            cur = torch.cuda.current_stream(self.device)
+            others = [s for (dev, _), s in _Side.streams.items() if dev == self.device.index]
+            if getattr(self, "step_stream", None) is not None:
+                others.append(self.step_stream)
+            for s in others:
+                if s != cur:
+                    cur.wait_stream(s)
             if self.use_sinks:  # LayerNorm parameter gradients queued for the end of backward belong to the slots too
                 from speechain_amd.functional import _LnFinish, _WgradQueue
 
@@ -238,6 +249,7 @@ class GradBucketReducer:
         """Start of a step.  With gradient sinks the kernels overwrite their slots, so nothing is zeroed: ``param.grad`` is
         dropped (autograd then adopts the slot view a kernel returns instead of adding into it).  Without sinks the flat
         buckets are zeroed and gradients stay views into them."""
+        self.step_stream = torch.cuda.current_stream(self.device) if self.cuda else None  # (the stream the step's main path runs on)
         if self.use_sinks:
             from speechain_amd.functional import GradSinks
 

@@ -352,14 +352,21 @@ class _Side:
     streams = {}
     enabled = True
 
-    def __init__(self, ref: torch.Tensor, wgrad_only: bool = False):
+    def __init__(self, ref: torch.Tensor, wgrad_only: bool = False, tag: str = "side"):
         """`wgrad_only`: the side work consists of weight-gradient products only -- no fork when those are deferred to the grouped
-        launch anyway (gradient sinks registered, bf16)."""
+        launch anyway (gradient sinks registered, bf16).  `tag`: one stream per (device, tag); a forward branch (see `entry`) takes a
+        tag of its own so that the fork/joins inside its own and the main path's backward nodes do not serialise the two."""
         self.on = _Side.enabled and ref.is_cuda
         if wgrad_only and _WgradQueue.enabled and GradSinks.table and ref.dtype == torch.bfloat16:
             self.on = False
+        if self.on and tag == "side" and any(t != "side" and d == ref.device.index and s == torch.cuda.current_stream(ref.device)
+                                             for (d, t), s in _Side.streams.items()):
+            # Inside a forward branch (or its backward): the branch already runs next to the main path.  [A second-level fork that shares
+            # the side stream with the main path's forks makes hipStreamEndCapture crash on ROCm 7.2 (tests/test_transformer_gpu.py:
+            # test_hipgraph_replay_matches_eager_steps without gradient sinks).]
+            self.on = False
         if self.on:
-            key = ref.device.index
+            key = (ref.device.index, tag)
             if key not in _Side.streams:
                 _Side.streams[key] = torch.cuda.Stream(device=ref.device)
             self.side = _Side.streams[key]
@@ -380,6 +387,26 @@ class _Side:
     def join(self):
         if self.on:
             self.main.wait_stream(self.side)
+
+    def entry(self, x: torch.Tensor) -> torch.Tensor:
+        """Call inside the ``with`` block on the tensor a whole forward BRANCH starts from (e.g. the CTC head + loss next to the decoder):
+        autograd runs a node's backward on the stream its forward ran on, so the branch's backward runs on the side stream too, next to
+        the backward of the main path; the returned identity's backward is the branch's last node and joins the side stream back."""
+        return _BranchEntry.apply(x, self.main) if (self.on and x.requires_grad) else x
+
+
+class _BranchEntry(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, main):
+        ctx.main = main
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        # everything the branch's backward launched (gradient-slot writes and operands queued for the grouped weight-gradient launch
+        # included) is ordered before whatever the main stream launches from here on
+        ctx.main.wait_stream(torch.cuda.current_stream(g.device))
+        return g, None
 
 
 import os as _os

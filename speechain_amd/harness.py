@@ -6,6 +6,8 @@ model/ar_asr.py:386-388,453-458,550) are not part of the hot path and are not re
 same order for parity tests, ``smoke()`` and ``bench.py``: [frontend -> SpecAugment -> Conv2dPrenet ->] encoder -> embedding ->
 decoder -> token heads -> ``(1 - w) * CE + w * CTC``.
 """
+import os
+
 import torch
 
 from speechain_amd import functional as Fn
@@ -15,6 +17,9 @@ from speechain_amd.module.postnet.token import TokenPostnet
 from speechain_amd.module.transformer.decoder import TransformerDecoder
 from speechain_amd.module.transformer.encoder import TransformerEncoder
 from speechain_amd.utilbox.train_util import make_mask_from_len
+
+
+_CTC_BRANCH = os.environ.get("SC_CTC_BRANCH", "1") == "1"  # (A/B knob)
 
 
 class Embed(torch.nn.Module):
@@ -54,11 +59,21 @@ class ASRTransformer(torch.nn.Module):
         dec_in = text.masked_fill(pos == (text_len - 1)[:, None], 0)  # (no indexed assignment: that would sync the host)
         dec_in, dec_len = dec_in[:, :-1], text_len - 1
         tgt_mask = make_mask_from_len(dec_len, max_len=dec_in.size(1))
+        # The CTC head and loss read only the encoder output: they run (forward AND backward) on a second stream next to the decoder --
+        # the CTC recursions occupy 32 workgroups for ~150 us, the decoder's launches fill the other CUs meanwhile.  SC_CTC_BRANCH=0: one stream.
+        side = Fn._Side(enc, tag="ctc") if _CTC_BRANCH else None
+        if side is not None:
+            with side:
+                ctc_logits = self.ctc_layer(side.entry(enc))
+                ctc = self.ctc_loss(ctc_logits, feat_len, text, text_len)
         dec, _, _, _ = self.decoder(tgt=self.embed(dec_in), src=enc, tgt_mask=tgt_mask, src_mask=enc_mask)
         logits = self.postnet(dec)
-        ctc_logits = self.ctc_layer(enc)
         ce = self.ce_loss(logits=logits, text=text, text_len=text_len)
-        ctc = self.ctc_loss(ctc_logits, feat_len, text, text_len)
+        if side is None:
+            ctc_logits = self.ctc_layer(enc)
+            ctc = self.ctc_loss(ctc_logits, feat_len, text, text_len)
+        else:
+            side.join()
         loss = (1 - self.ctc_weight) * ce + self.ctc_weight * ctc
         # (enc_hidden: the per-layer encoder outputs, encoder.py:339-343 -- a trainer that cuts backward into pieces uses them as cut points)
         return dict(enc=enc, logits=logits, ctc_logits=ctc_logits, ce=ce, ctc=ctc, loss=loss, enc_hidden=enc_hidden)
