@@ -63,12 +63,19 @@ class MultiHeadedAttention(Module):
         return Fn.linear(context, [self.output_layer.weight], [self.output_layer.bias]), score_soft
 
     def forward(self, k: torch.Tensor, v: torch.Tensor, q: torch.Tensor, mask: torch.Tensor = None, *, _residual=None,
-                _res_drop: float = 0.0, _causal: bool = False):
+                _res_drop: float = 0.0, _causal: bool = False, _kv=None):
+        """``_kv``: ``(keys | values buffer (B, Tk, 2 d) already projected from k / v, callable to run before it is read)`` -- the decoder
+        projects the encoder output for all its layers up front on a second stream (decoder.py)."""
         same_kv, same_all = k is v, (k is v) and (v is q)
         qc = Fn.to_compute(q)
-        kc = qc if same_all else Fn.to_compute(k)
-        vc = kc if same_kv else Fn.to_compute(v)
-        q_buf, kv_buf, iq, ik, iv = self._project(kc, vc, qc)
+        if _kv is not None:
+            Q = self.q_layer
+            q_buf, kv_buf, iq, ik, iv = Fn.linear(qc, [Q.weight], [Q.bias]), _kv[0], 0, 0, 1
+            _kv[1]()
+        else:
+            kc = qc if same_all else Fn.to_compute(k)
+            vc = kc if same_kv else Fn.to_compute(v)
+            q_buf, kv_buf, iq, ik, iv = self._project(kc, vc, qc)
         p = self.dropout.p if self.training else 0.0
         context, probs = Fn.attention_core(q_buf, kv_buf, iq, ik, iv, self.num_heads, self.d_model, mask, _causal, self.scale, p)
         res = Fn.to_compute(_residual, context.dtype) if _residual is not None else None

@@ -7,6 +7,8 @@ Quirks kept: the enc-dec attention never scales by head (:76-78), the decoder ne
 layers (:271-285), ``emb_scale`` defaults to True (:187).  The causal mask is not materialised: the softmax kernel
 combines the (B,1,L) padding mask with ``k <= q``.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -16,6 +18,9 @@ from speechain_amd.module.transformer.attention import MultiHeadedAttention
 from speechain_amd.module.transformer.encoder import _ln, _ln_res
 from speechain_amd.module.transformer.feed_forward import PositionwiseFeedForward
 from speechain_amd.module.transformer.pos_enc import PositionalEncoding
+
+
+_CROSSKV_BRANCH = os.environ.get("SC_CROSSKV_BRANCH", "1") == "1"  # (A/B knob)
 
 
 class TransformerDecoderLayer(Module):
@@ -32,7 +37,8 @@ class TransformerDecoderLayer(Module):
         self.fdfwd_ln = nn.LayerNorm(d_model, eps=1e-6)
         self.dropout = nn.Dropout(res_dropout)
 
-    def forward(self, tgt: torch.Tensor, src: torch.Tensor, tgt_mask: torch.Tensor, src_mask: torch.Tensor, *, _causal: bool = False):
+    def forward(self, tgt: torch.Tensor, src: torch.Tensor, tgt_mask: torch.Tensor, src_mask: torch.Tensor, *, _causal: bool = False,
+                _cross_kv=None):
         """``tgt_mask`` is the reference's dense (B, L, L) mask, or -- with ``_causal=True`` -- the (B, 1, L) padding mask."""
         tgt, src = Fn.to_compute(tgt), Fn.to_compute(src)
         p = self.dropout.p if self.training else 0.0
@@ -43,7 +49,7 @@ class TransformerDecoderLayer(Module):
         if not first:
             x = _ln(self.self_att_ln, x)
         x_norm, x = _ln_res(self.encdec_att_ln, x) if first else (x, x)
-        y, encdec_attmat = self.encdec_att(src, src, x_norm, mask=src_mask, _residual=x, _res_drop=p)
+        y, encdec_attmat = self.encdec_att(src, src, x_norm, mask=src_mask, _residual=x, _res_drop=p, _kv=_cross_kv)
         if not first:
             y = _ln(self.encdec_att_ln, y)
         y_norm, y = _ln_res(self.fdfwd_ln, y) if first else (y, y)
@@ -128,8 +134,20 @@ class TransformerDecoder(Module):
         tgt = self.posenc(tgt)
         src = Fn.to_compute(src)
         self_attmat, encdec_attmat, hidden = [], [], []
-        for layer in self.trfm_layers:
-            tgt, _self, _encdec = layer(tgt=tgt, tgt_mask=tgt_mask, src=src, src_mask=src_mask, _causal=True)
+        # The encoder-side keys | values of every layer depend on the encoder output alone: they are projected up front on a second stream,
+        # next to the first layer's self-attention -- and, since autograd runs a node's backward on its forward's stream, their data
+        # gradients (products over all the encoder frames) run next to the backward of the decoder's own small products.
+        # SC_CROSSKV_BRANCH=0: projected inside each layer, on one stream.
+        cross = [None] * len(self.trfm_layers)
+        if _CROSSKV_BRANCH and src.is_cuda:
+            side = Fn._Side(src, tag="crosskv")
+            with side:
+                s_in = side.entry(src)
+                kvs = [layer.cross_kv(s_in) for layer in self.trfm_layers]
+            nop = lambda: None
+            cross = [(kv, side.join if i == 0 else nop) for i, kv in enumerate(kvs)]
+        for layer, ckv in zip(self.trfm_layers, cross):
+            tgt, _self, _encdec = layer(tgt=tgt, tgt_mask=tgt_mask, src=src, src_mask=src_mask, _causal=True, _cross_kv=ckv)
             self_attmat.append(_self)
             encdec_attmat.append(_encdec)
             hidden.append(tgt)
