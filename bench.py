@@ -155,7 +155,14 @@ class ASRTrainStepWorkload:
                 if p.dim() > 1:
                     torch.nn.init.xavier_normal_(p)
         self.params = [p for m in (self.prenet, self.model) for p in m.parameters()]
-        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, adjacent=attention_fusion_groups(self.model))
+        # The gradient buckets travel on a communicator of their own: torch keeps ONE stream per (device, process group) for its
+        # collectives, so on the default group the small all-gather of the next batch's normalisation statistics (head stream, followed by
+        # SpecAugment's host-side reads) would queue behind this step's bucket all-reduces and tie the host to the end of backward.
+        grad_pg = None
+        if distributed and os.environ.get("BENCH_GRAD_PG", "1") == "1":
+            import torch.distributed as dist
+            grad_pg = dist.new_group(backend="nccl")
+        self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, process_group=grad_pg, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
         self.lr = torch.tensor([2e-3], device=device)
         # clip at 5.0 + Adam(0.9, 0.98, 1e-9) over the flat buckets in two launches (csrc/optim.hip); BENCH_TORCH_ADAM=1: stock torch ops
