@@ -412,6 +412,67 @@ def test_gradient_sinks_match_plain_autograd():
         Fn.set_compute_dtype(None)
 
 
+@pytest.mark.parametrize("sinks", [False, True])
+def test_side_stream_branches_match_one_stream(monkeypatch, sinks):
+    """The CTC head + loss and the decoder's encoder-side key|value projections run on streams of their own, forward and backward
+    (harness.py, decoder.py): losses and every parameter gradient must equal the one-stream run, eagerly and step after step (a missing
+    join shows up as a stale or half-written gradient), with plain autograd accumulation and with the gradient sinks + grouped weight
+    gradients of the training step."""
+    from speechain_amd import harness
+    from speechain_amd.ddp import GradBucketReducer, attention_fusion_groups
+    from speechain_amd.module.transformer import decoder as dec_mod
+
+    Fn.set_compute_dtype(torch.bfloat16 if sinks else torch.float32)
+    try:
+        V = 31
+
+        def make():
+            torch.manual_seed(21)
+            return harness.ASRTransformer(d_model=128, num_heads=2, enc_layers=2, dec_layers=3, fdfwd_dim=256, vocab_size=V, dropout=0.0,
+                                          posenc_maxlen=200).cuda().train()
+
+        gen = torch.Generator().manual_seed(22)
+        x = torch.randn(6, 90, 128, generator=gen).cuda()
+        xlen = torch.tensor([90, 81, 77, 60, 45, 33]).cuda()
+        text = torch.randint(1, V - 2, (6, 12), generator=gen)
+        tl = torch.tensor([12, 11, 9, 8, 6, 5])
+        for i, l in enumerate(tl):
+            text[i, 0] = V - 1
+            text[i, l - 1] = V - 1
+            text[i, l:] = 0
+        text, tl = text.cuda(), tl.cuda()
+
+        def run(branches: bool):
+            monkeypatch.setattr(harness, "_CTC_BRANCH", branches)
+            monkeypatch.setattr(dec_mod, "_CROSSKV_BRANCH", branches)
+            Fn.GradSinks.clear()
+            m = make()
+            red = GradBucketReducer(m.parameters(), bucket_mb=0.25, adjacent=attention_fusion_groups(m)) if sinks else None
+            outs = []
+            for _ in range(3):
+                if red is not None:
+                    red.zero_grad()
+                else:
+                    m.zero_grad(set_to_none=True)
+                out = m(x, xlen, text, tl)
+                out["loss"].backward()
+                if red is not None:
+                    red.wait()
+                torch.cuda.synchronize()
+                outs.append((out["loss"].detach().clone(), out["ctc"].detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+            return outs
+
+        one, two = run(False), run(True)
+        tol = dict(atol=2e-3, rtol=2e-2) if sinks else dict(atol=1e-5, rtol=1e-4)  # (bf16: the encoder-output gradient is summed in another order)
+        for (l1, c1, g1), (l2, c2, g2) in zip(one, two):
+            assert torch.allclose(l1, l2, atol=1e-6, rtol=1e-6) and torch.allclose(c1, c2, atol=1e-6, rtol=1e-6), (l1, l2, c1, c2)
+            for n in g1:
+                assert torch.allclose(g1[n].float(), g2[n].float(), **tol), (n, float((g1[n].float() - g2[n].float()).abs().max()))
+    finally:
+        Fn.GradSinks.clear()
+        Fn.set_compute_dtype(None)
+
+
 def test_batched_weight_refresh_matches_lazy_casts():
     """weights.refresh() re-casts every cached bf16 copy (plain, fused q|k|v, transposed) in one launch; after an in-place
     parameter update the refreshed copies must equal freshly computed ones."""
