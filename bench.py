@@ -518,6 +518,8 @@ class TTSTrainStepWorkload:
         self.ev, self.flops, self.launch_flops, self.launch_kernels = [], 0.0, [], []
         self.targets, self.g_body, self.g_tail, self.loss = None, None, None, None
         self.use_graph = os.environ.get("BENCH_NO_GRAPH", "0") != "1"
+        self.head_stream = torch.cuda.Stream(device=device) if (os.environ.get("BENCH_NO_PREFETCH", "0") != "1" and self.use_graph) else None
+        self.next_head, self.copied = None, None
 
     def _body(self):
         from speechain_amd import functional as Fn
@@ -538,7 +540,16 @@ class TTSTrainStepWorkload:
         self.lr.fill_(384 ** -0.5 * min(self.nstep ** -0.5, self.nstep * 6000 ** -1.5))
         # head, eager: frontend (mel + energy), the three normalisations (their running statistics are re-created on every call), frame counts per
         # token, per-token pitch / energy targets -> the static inputs of the captured body
-        tg = self.model.prepare(*self.batch[2:], epoch=1)
+        # Like the ASR workload's head, it depends on the data only: the head of batch i+1 runs on a second stream while the graphs of batch i
+        # are replayed (every timed step still runs one head and one body).  BENCH_NO_PREFETCH=1: in line.
+        main = torch.cuda.current_stream()
+        if self.head_stream is None:
+            tg = self.model.prepare(*self.batch[2:], epoch=1)
+        else:
+            if self.next_head is None:
+                self._prefetch_next(main)
+            tg, ev = self.next_head
+            main.wait_event(ev)
         if self.targets is None:
             self.targets = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tg.items()}
         else:
@@ -546,6 +557,10 @@ class TTSTrainStepWorkload:
                 for k, v in tg.items():
                     if torch.is_tensor(v):
                         self.targets[k].copy_(v)
+        if self.head_stream is not None:  # the head stream may reuse the memory of `tg` only after these copies have run
+            self.copied = torch.cuda.Event()
+            self.copied.record(main)
+            self.next_head = None
         # (more than one rank: the body is replayed as one graph, then every bucket is all-reduced, then the optimizer graph -- no overlap of
         # the 35 M parameters' gradients with backward, but none of the eager path's launch overhead either: 16.2 -> 12.35 ms on a one-rank group)
         graph = self.use_graph and not instrument and self.nstep > 3
@@ -564,6 +579,8 @@ class TTSTrainStepWorkload:
             if self.reducer.multi:
                 self.reducer.reduce_all_now()
             self.g_tail.replay()
+            if self.head_stream is not None:
+                self._prefetch_next(main)
             return self.loss
         if instrument:
             lib.timing = {"sc_gemm": self.ev, "sc_gemm_splitk": self.ev, "sc_wgrad_grouped": self.ev}
@@ -577,6 +594,17 @@ class TTSTrainStepWorkload:
             self.launch_kernels += lib.kernel_log
             lib.timing = lib.flop_log = lib.kernel_log = None
         return loss
+
+    def _prefetch_next(self, main):
+        with torch.cuda.stream(self.head_stream):
+            if self.copied is not None:
+                self.head_stream.wait_event(self.copied)
+            else:
+                self.head_stream.wait_stream(main)
+            tg = self.model.prepare(*self.batch[2:], epoch=1)
+            ev = torch.cuda.Event()
+            ev.record(self.head_stream)
+        self.next_head = (tg, ev)
 
     roofline = None  # bound below: the GEMM roofline code of the ASR workload works on the same logs
 
