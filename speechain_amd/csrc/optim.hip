@@ -12,7 +12,9 @@
 namespace {
 
 constexpr int MAX_BUCKETS = 48;
-constexpr long long CHUNK = 65536;  // elements per workgroup
+// elements per workgroup.  78 M parameters: 65536 (1190 workgroups, 64 rounds of 4 loads per thread) 397 us for the Adam launch, 16384 357 us,
+// 8192 320 us, 4096 354 us (rocprofv3 rows of the bench step)
+constexpr long long CHUNK = 8192;
 
 struct Buckets {
   const float* g[MAX_BUCKETS];
