@@ -599,9 +599,22 @@ SC_API int sc_layernorm_fwd(int dtype, const void* x, const float* gamma, const 
   return SC_OK;
 }
 
+// The partition of sc_layernorm_bwd: rows per workgroup (4 waves, one row each at a time) and the number of workgroups, i.e. of partial
+// dgamma / dbeta rows.  (A/B knobs: SC_LN_BWD_ROWS = rows per workgroup aimed for, SC_LN_BWD_CAP = most workgroups.)
+static void ln_bwd_partition(long long R, int* rpb_out, long long* blocks_out) {
+  static const long long rows = [] { const char* e = getenv("SC_LN_BWD_ROWS"); return e ? atoll(e) : 8LL; }();
+  static const long long cap = [] { const char* e = getenv("SC_LN_BWD_CAP"); return e ? atoll(e) : 1024LL; }();
+  long long blocks = (R + rows - 1) / rows;
+  if (blocks > cap) blocks = cap;
+  const int rpb = (int)((R + blocks - 1) / blocks);
+  *rpb_out = rpb;
+  *blocks_out = (R + rpb - 1) / rpb;
+}
+
 SC_API long long sc_layernorm_bwd_workspace(long long R, int D) {
-  long long blocks = (R + 7) / 8;
-  if (blocks > 1024) blocks = 1024;
+  int rpb;
+  long long blocks;
+  ln_bwd_partition(R, &rpb, &blocks);
   return blocks * 2 * D * (long long)sizeof(float);
 }
 
@@ -616,10 +629,9 @@ static int layernorm_bwd_impl(int dtype, const void* dy, const void* x, const fl
   SC_CHECK_ARG(stages == 1 || stages == 3, "sc_layernorm_bwd: stages is 1 (dx + partial sums; finish with sc_layernorm_bwd_finish) or 3 (everything)");
   SC_CHECK_ARG(R >= 1 && D >= 1 && D <= 64 * LN_MAX, "sc_layernorm_bwd: need 1 <= D <= %d, got %d", 64 * LN_MAX, D);
   SC_CHECK_ARG(ws_bytes >= sc_layernorm_bwd_workspace(R, D), "sc_layernorm_bwd: workspace too small");
-  long long blocks = (R + 7) / 8;
-  if (blocks > 1024) blocks = 1024;
-  const int rpb = (int)((R + blocks - 1) / blocks);
-  blocks = (R + rpb - 1) / rpb;
+  int rpb;
+  long long blocks;
+  ln_bwd_partition(R, &rpb, &blocks);
   const size_t smem = (size_t)8 * D * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_layernorm_bwd: D too large for the LDS reduction");
   const bool vec = dtype == 1 && D % 8 == 0 && D <= 2048 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dres | (uintptr_t)dz) % 16 == 0);
@@ -673,10 +685,9 @@ SC_API int sc_layernorm_bwd_finish(int n, const void* const* workspaces, const l
     for (int i = 0; i < m; ++i) {
       const int k = i0 + i;
       SC_CHECK_ARG(workspaces[k] && dgamma[k] && dbeta[k] && R[k] >= 1 && D[k] >= 1, "sc_layernorm_bwd_finish: bad entry %d", k);
-      long long blocks = (R[k] + 7) / 8;  // (the partition sc_layernorm_bwd uses)
-      if (blocks > 1024) blocks = 1024;
-      const int rpb = (int)((R[k] + blocks - 1) / blocks);
-      blocks = (R[k] + rpb - 1) / rpb;
+      int rpb;
+      long long blocks;
+      ln_bwd_partition(R[k], &rpb, &blocks);
       b.part[i] = (const float*)workspaces[k];
       b.out0[i] = dgamma[k];
       b.out1[i] = dbeta[k];
