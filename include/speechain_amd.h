@@ -375,6 +375,10 @@ int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long*
 
 /* dtype casts (0 = f32, 1 = bf16) and the transposed cast out[c][r] = in[r][c] of an (R, C) f32 matrix. */
 int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
+/* Zero-padded row image of a (B, T, C) bf16 tensor: rows_total rows of C, utterance b at rows b (T + 2 r) .. with r zero rows on either side,
+ * zero rows behind the last utterance.  With it a 'same' Conv1d (speechain/module/prenet/conv1d.py:Conv1dEv, the conv-type feed-forward of
+ * speechain/module/transformer/feed_forward.py:71-95) is ONE sc_gemm over overlapping rows (lda = C < K = k C) instead of im2col + GEMM. */
+int sc_pad_rows(const void* x, int B, int T, int C, int r, void* out, long long rows_total, hipStream_t stream);
 /* dW (V, D) f32 of out = table[ids] from dy (N, D; row stride ld): autograd of the token embedding (speechain/module/prenet/embed.py:55-66).
  * Deterministic, no atomics (the first position holding an id sums all of that id's rows in position order); the row of padding_idx
  * (nn.Embedding's) stays zero; pass a negative padding_idx for none.  ids in [0, V). */

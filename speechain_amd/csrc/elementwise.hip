@@ -89,6 +89,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, const void
   }
 }
 
+// (see sc_pad_rows) one 16-byte chunk per thread and round
+__global__ __launch_bounds__(256) void pad_rows_kernel(const uint4* x, int B, int T, int C8, int r, uint4* out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int Tp = T + 2 * r;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long row = i / C8;
+    const int c = (int)(i - row * C8);
+    const long long b = row / Tp;
+    const int t = (int)(row - b * Tp) - r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (b < B && t >= 0 && t < T) v = x[(b * T + t) * C8 + c];
+    out[i] = v;
+  }
+}
+
 // One launch refreshing many compute-dtype weight copies: descriptor d covers tiles [tile0, next.tile0) of a (rows, cols)
 // f32 matrix; every 32 x 32 tile is written to dst (same layout, row stride ld_dst) and/or dst_t (transposed, row stride
 // ld_dst_t).  Layout of sc_cast_desc: include/speechain_amd.h.
@@ -249,6 +264,20 @@ SC_API int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long 
   else if (dtype_in == 0 && dtype_out == 0) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
   else hipLaunchKernelGGL((cast_kernel<unsigned short, unsigned short>), dim3(grid_for(n)), dim3(256), 0, stream, in, out, n);
   SC_LAUNCH_CHECK("cast_kernel");
+  return SC_OK;
+}
+
+// Zero-padded row image of a (B, T, C) bf16 tensor for a 'same' Conv1d evaluated WITHOUT an im2col copy (functional._ConvLinear):
+// out holds rows_total rows of C; utterance b occupies rows b (T + 2 r) .. + T + 2 r - 1 = r zero rows, its T rows, r zero rows; rows
+// behind the last utterance are zero.  The GEMM then reads "row" t of utterance b as the k C contiguous elements that start at padded
+// row t (leading dimension C < K: rows overlap), i.e. [x[t - r], .., x[t + r]] -- the matrix sc_im2col would have written.
+SC_API int sc_pad_rows(const void* x, int B, int T, int C, int r, void* out, long long rows_total, hipStream_t stream) {
+  SC_CHECK_ARG(x && out && B >= 1 && T >= 1 && C >= 8 && C % 8 == 0 && r >= 0 && rows_total >= (long long)B * (T + 2 * r),
+               "sc_pad_rows: bad arguments (B=%d T=%d C=%d r=%d rows=%lld; bf16, C %% 8 == 0)", B, T, C, r, rows_total);
+  SC_CHECK_ARG(((uintptr_t)x | (uintptr_t)out) % 16 == 0, "sc_pad_rows: tensors must be 16-byte aligned");
+  const long long n = rows_total * (C / 8);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const uint4*)x, B, T, C / 8, r, (uint4*)out, n);
+  SC_LAUNCH_CHECK("pad_rows_kernel");
   return SC_OK;
 }
 

@@ -1483,7 +1483,8 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
   SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_gemm: dtype must be 0 (f32) or 1 (bf16)");
   SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 1 && nb1 >= 1 && nb2 >= 1, "sc_gemm: bad sizes M=%d N=%d K=%d nb=%dx%d", M, N, K, nb1, nb2);
   SC_CHECK_ARG((long long)nb1 * nb2 <= 65535, "sc_gemm: batch %lld too large", (long long)nb1 * nb2);
-  SC_CHECK_ARG(lda >= (ta ? M : K) && ldb >= (tb ? N : K) && ldc >= N, "sc_gemm: leading dimension too small");
+  // (A not transposed: lda < K is allowed -- overlapping rows, the im2col-free 'same' Conv1d of functional._ConvLinear, see sc_pad_rows)
+  SC_CHECK_ARG(lda >= (ta ? M : 1) && ldb >= (tb ? N : K) && ldc >= N, "sc_gemm: leading dimension too small");
   SC_CHECK_ARG(aux_mode >= AUX_NONE && aux_mode <= AUX_MUL && (aux_mode == AUX_NONE || aux), "sc_gemm: aux_mode %d (0..3) without aux or out of range", aux_mode);
   SC_CHECK_ARG((act & 0xFF) <= ACT_GELU && (act & ~(0xFF | ACT_PRE_GRAD)) == 0, "sc_gemm: bad act code %d", act);
   SC_CHECK_ARG(!(act & ACT_PRE_GRAD) || pre_out, "sc_gemm: the pre-gradient flag needs pre_out");
@@ -1522,7 +1523,10 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
       static const long long bigmin = [] { const char* e = getenv("SC_GEMM_BIG_MIN"); return e ? atoll(e) : 200LL; }();  // (A/B knob; 7968 x 1536 x 512, 192 tiles of 256 x 256: 27.4 us, as 756 tiles of 128 x 128: 26.3 us)
-      if (big >= bigmin && N > 128) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4, 0>(a, nb, stream); }
+      // (a batched product whose M is far from a multiple of 256 -- the per-utterance products of the im2col-free Conv1d: T = 640 frames
+      //  would fill 3 row tiles of 256 to 83 %, T = 128 tokens one to 50 % -- takes 128-row tiles when those waste less)
+      const bool ragged256 = (long long)sc_cdiv(M, 256) * 256 * 100 > (long long)sc_cdiv(M, 128) * 128 * 108;
+      if (big >= bigmin && N > 128 && !ragged256) { g_last_gemm_kernel = 2; return launch_dma<2, 4, 4, 0>(a, nb, stream); }
       // Very few tiles (the decoder's M = 2016, N = 512 products: 64 tiles of 128 x 128, 128 of 64 x 128): 64 x 64 tiles, two waves each,
       // put a workgroup on every CU.  Step-level A/B (40 steps, alternating): 12.35 / 12.36 / 12.55 ms with them vs 12.60 / 12.61 / 12.69
       // without; thresholds of 80, 128 and 192 tiles measure the same (12.53 .. 12.64 on another box), 256 hurts (12.99).

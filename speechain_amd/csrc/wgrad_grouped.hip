@@ -408,7 +408,7 @@ SC_API int sc_wgrad_grouped_last_tile(void) { return g_last_tile; }
 // 1 if a product of this shape can go through sc_wgrad_grouped (whole 32-token K tiles, 16-byte aligned rows on both sides)
 SC_API int sc_wgrad_grouped_supported(int n_out, int n_in, int tokens, long long ldz, long long ldx) {
   return n_out >= 8 && n_in >= 8 && n_out % 8 == 0 && n_in % 8 == 0 && tokens >= BK && tokens % BK == 0 && ldz % 8 == 0 && ldx % 8 == 0 &&
-         ldz >= n_out && ldx >= n_in && ldz < (1LL << 31) && ldx < (1LL << 31);
+         ldz >= n_out && ldx >= 8 && ldz < (1LL << 31) && ldx < (1LL << 31);  // (ldx < n_in: overlapping rows, see sc_pad_rows)
 }
 
 // bytes of device workspace sc_wgrad_grouped needs for its schedule table (for either tile size)

@@ -46,6 +46,7 @@ class DropoutState:
     base_seed = None
     offset = 0
     cells = {}
+    advances = 0  # advance() calls since the seed was set: a cell created later starts from the same value as the existing ones
 
     @classmethod
     def _cell(cls, device: torch.device) -> torch.Tensor:
@@ -53,7 +54,8 @@ class DropoutState:
         if key not in cls.cells:
             if cls.base_seed is None:
                 cls.base_seed = torch.initial_seed() & 0x3FFFFFFFFFFFFFFF
-            cls.cells[key] = torch.tensor([cls.base_seed], dtype=torch.int64, device=device)
+            v = (cls.base_seed + cls.advances * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            cls.cells[key] = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v], dtype=torch.int64, device=device)
         return cls.cells[key]
 
     @classmethod
@@ -69,12 +71,13 @@ class DropoutState:
         """New seed for the next step (a device-side add: capturable), offsets restart from zero."""
         for c in cls.cells.values():
             c.add_(0x9E3779B97F4A7C15 - (1 << 64))  # odd constant: the int64 cell walks all 2^64 values
+        cls.advances += 1
         cls.offset = 0
         _MaskedGrad.sites.clear()  # (sites noted in the previous step whose output never reached a LayerNorm)
 
     @classmethod
     def reset(cls, seed: int):
-        cls.base_seed, cls.offset = seed & 0x3FFFFFFFFFFFFFFF, 0
+        cls.base_seed, cls.offset, cls.advances = seed & 0x3FFFFFFFFFFFFFFF, 0, 0
         for c in cls.cells.values():
             c.fill_(cls.base_seed)
 
@@ -322,6 +325,17 @@ class GradSinks:
         _LnFinish.reset()  # (entries of a backward call that raised must not survive into the next step)
         _WgradQueue.reset()
         _MaskedGrad.reset()
+
+    @classmethod
+    def peek(cls, params: Sequence[torch.Tensor]) -> bool:
+        """Would `take(params)` succeed now?  (Nothing is marked.)"""
+        end = None
+        for p in params:
+            e = cls.table.get(id(p))
+            if e is None or e[0]() is not p or cls.used.get(id(p)) == cls.step or (end is not None and (e[1] is not flat or e[2] != end)):
+                return False
+            flat, end = e[1], e[2] + e[3]
+        return bool(params)
 
     @classmethod
     def take(cls, params: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -728,6 +742,116 @@ def linear_act(x, w, b, activation: str, drop_p: float = 0.0):
     if activation not in ACT:
         raise NotImplementedError(f"speechain_amd feed-forward implements ReLU and GELU, got {activation}")
     return _LinearAct.apply(x, w, b, ACT[activation], float(drop_p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 'same' Conv1d as ONE product over overlapping rows of a zero-padded image (no im2col copy, no col2im):
+#     y = dropout(act(conv1d(x, w) + b)) [+ residual]        x (B, T, C), w (N, C, k) -- an nn.Conv1d weight --, k odd
+# ---------------------------------------------------------------------------------------------------------------------
+
+_CONV_DIRECT = _os.environ.get("SC_CONV_DIRECT", "1") == "1"  # (A/B knob: 0 = shifted_cat (im2col) + linear everywhere)
+
+
+def _pad_rows(x3: torch.Tensor, r: int) -> torch.Tensor:
+    """(B, T, C) bf16 -> (rows, C) image: utterance b at rows b (T + 2 r) .. with r zero rows on either side, zero rows behind the last
+    utterance (csrc/elementwise.hip:sc_pad_rows).  rows = B (T + 2 r) rounded up to 32 (the grouped weight-gradient launch contracts over
+    whole 32-row tiles) + 32 (the last windows read up to 2 r rows further)."""
+    B, T, C = x3.shape
+    rows = (B * (T + 2 * r) + 31) // 32 * 32 + 32
+    out = torch.empty(rows, C, dtype=x3.dtype, device=x3.device)
+    lib.call("sc_pad_rows", _p(x3), B, T, C, r, _p(out), rows, stream())
+    return out
+
+
+def conv_direct_ok(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> bool:
+    """The im2col-free path serves the training configuration it was built for: bf16 compute on the GPU, channel counts in whole 16-byte
+    chunks, odd taps, and the weight's (and bias') gradient written into bucket slots by the grouped launch (GradSinks registered) --
+    everything else keeps shifted_cat + linear."""
+    return (_CONV_DIRECT and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and w.dim() == 3 and w.size(2) > 1 and w.size(2) % 2 == 1
+            and x.size(2) == w.size(1) and x.size(2) % 8 == 0 and w.size(0) % 8 == 0 and w.is_leaf and _WgradQueue.enabled
+            and id(w) in GradSinks.table and (b is None or id(b) in GradSinks.table))
+
+
+class _ConvLinear(torch.autograd.Function):
+    """Row t of utterance b of the im2col matrix [x[t - r], .., x[t + r]] is the k C contiguous elements that start at padded row t of the
+    image `_pad_rows` writes, so the GEMM reads it in place with leading dimension C (rows overlap), batched over the utterances; the
+    output is the contiguous (B, T, N) tensor.  Backward: the same trick on the zero-padded gradient gives the data gradient as one
+    product against the taps in reverse order (dx[t] = sum_j dz[t - r + j] W[k - 1 - j]) -- no (M, k C) column gradient, no col2im --
+    and the weight gradient joins the grouped launch with both operands as overlapping-row views.  Arithmetic and dropout indices are
+    those of `linear(shifted_cat(x, k), ...)`: the results are identical bit for bit."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w, b, act, drop_p):
+        require_gpu(x, "conv1d")
+        x = x if x.is_contiguous() else x.contiguous()
+        B, T, C = x.shape
+        N, _, k = w.shape
+        r = (k - 1) // 2
+        Tp, M = T + 2 * r, B * T
+        xp = _pad_rows(x, r)
+        W = weights.fused([w], x.dtype)  # (N, k C), column = tap * C + channel
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        pre = torch.empty(M, N, dtype=x.dtype, device=x.device) if act else None
+        seed, off = DropoutState.next(M * N, x.device) if drop_p > 0 else (0, 0)
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(M, N)
+            res2 = res2 if res2.is_contiguous() else res2.contiguous()
+        gemm(BF16, _p(xp), _p(W), _p(y), T, N, k * C, C, k * C, N, nb=(B, 1), sA=(Tp * C, 0), sC=(T * N, 0),
+             bias=b.detach() if b is not None else None, act=act, pre_out=_p(pre), aux=_p(res2), ldaux=N,
+             aux_mode=1 if res2 is not None else 0, drop=(drop_p, seed, off))
+        ctx.save_for_backward(xp, pre, w)
+        ctx.bias_params = [b] if b is not None else []
+        ctx.meta = (B, T, C, N, k, act, drop_p, seed, off, residual is not None)
+        if not act:
+            _MaskedGrad.note_site(y, drop_p, seed, off)
+        return y.view(B, T, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, pre, w = ctx.saved_tensors
+        B, T, C, N, k, act, drop_p, seed, off, has_res = ctx.meta
+        r = (k - 1) // 2
+        Tp, M = T + 2 * r, B * T
+        dy2 = dy.reshape(M, N)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        if act:
+            dz = torch.empty_like(pre)
+            lib.call("sc_act_bwd", BF16, _p(dy2), _p(pre), _p(dz), dz.numel(), act, float(drop_p), seed, off, stream())
+        else:
+            dz = _masked_grad(dy2, drop_p, seed, off)
+        dzp = _pad_rows(dz.view(B, T, N), r)
+        tokens = (B * Tp + 31) // 32 * 32
+        # window i of xp (rows i .. i + k - 1) belongs to the output position whose gradient sits at row i + r of dzp; the windows that
+        # straddle two utterances meet zero rows there
+        x2v = xp.as_strided((tokens, k * C), (C, 1))
+        dzv = dzp.as_strided((tokens, N), (N, 1), r * N)
+        bp = ctx.bias_params
+        if not (GradSinks.peek([w]) and (not bp or GradSinks.peek(bp))):
+            x2v = x2v.contiguous()  # (not the configuration this path is for: the immediate weight-gradient kernels want distinct rows)
+        dW, db = wgrad(BF16, dzv, x2v, [w], bias=True, bias_params=bp) if bp else (wgrad(BF16, dzv, x2v, [w]), None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wt = weights.fused_t([w], dz.dtype).view(k, C, N)  # [tap][channel][out]
+            D = torch.stack([Wt[k - 1 - j] for j in range(k)], dim=1).view(C, k * N)  # [channel][j * N + out] = w[out][channel][k - 1 - j]
+            dx = torch.empty(M, C, dtype=dz.dtype, device=dz.device)
+            gemm(BF16, _p(dzp), _p(D), _p(dx), T, C, k * N, N, k * N, C, nb=(B, 1), sA=(Tp * N, 0), sC=(T * C, 0))
+            dx = dx.view(B, T, C)
+        return dx, (dy if has_res else None), dW.view_as(w), db, None, None
+
+
+def conv_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], activation: Optional[str] = None, drop_p: float = 0.0,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """'same' Conv1d over (B, T, C) with an nn.Conv1d weight (N, C, k): the im2col-free path when `conv_direct_ok`, else
+    `linear[_act](shifted_cat(x, k), ...)` -- the same arithmetic either way."""
+    if activation not in ACT:
+        raise NotImplementedError(f"speechain_amd conv feed-forward implements ReLU and GELU, got {activation}")
+    if conv_direct_ok(x, w, b) and (residual is None or ACT[activation] == 0):
+        return _ConvLinear.apply(x, residual, w, b, ACT[activation], float(drop_p))
+    col = shifted_cat(x, w.size(2))
+    if ACT[activation]:
+        return linear_act(col, w, b, activation, drop_p)
+    return linear(col, [w], [b], drop_p=drop_p, residual=residual)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

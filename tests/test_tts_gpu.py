@@ -184,3 +184,58 @@ def test_conv1d_postnet_eval_and_train_vs_oracle(mode):
     finally:
         Fn.set_compute_dtype(None)
         Fn.weights.invalidate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,k", [(50, 3), (128, 3), (37, 5)])
+def test_conv_feed_forward_without_im2col_equals_the_im2col_path(monkeypatch, T, k):
+    """functional._ConvLinear (one product over overlapping rows of a zero-padded image, data gradient against the reversed taps,
+    weight gradient from overlapping-row views in the grouped launch) against shifted_cat + linear on the conv-type feed-forward of the
+    FastSpeech2 recipes: identical outputs (same arithmetic, same dropout indices); gradients within bf16 rounding (the old data gradient
+    rounds each tap's contribution to bf16 before col2im adds them)."""
+    from speechain_amd import functional as Fn
+    from speechain_amd.ddp import GradBucketReducer
+    from speechain_amd.module.transformer.feed_forward import PositionwiseFeedForward
+
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        B, d, dff = 3, 64, 256
+        gen = torch.Generator().manual_seed(5)
+        x0 = torch.randn(B, T, d, generator=gen).cuda()
+        res0 = torch.randn(B, T, d, generator=gen).cuda()
+        dy = torch.randn(B, T, d, generator=gen).cuda().bfloat16()
+
+        def run(direct: bool):
+            monkeypatch.setattr(Fn, "_CONV_DIRECT", direct)
+            Fn.GradSinks.clear()
+            Fn.weights.invalidate()
+            torch.manual_seed(3)
+            ff = PositionwiseFeedForward(d_model=d, fdfwd_dim=dff, fdfwd_type="conv", fdfwd_activation="ReLU", fdfwd_args={"kernel_size": k},
+                                         dropout=0.1).cuda().train()
+            red = GradBucketReducer(ff.parameters(), bucket_mb=0.25)
+            outs = []
+            for step in range(2):  # twice: no stale slots, no double counting
+                Fn.DropoutState.reset(1234)
+                Fn.DropoutState.advance()
+                red.zero_grad()
+                x = x0.clone().bfloat16().requires_grad_(True)
+                y = ff(x, _residual=res0.bfloat16(), _res_drop=0.1)
+                y.backward(dy)
+                red.wait()
+                torch.cuda.synchronize()
+                outs.append((y.detach().float().clone(), x.grad.float().clone(), {n: p.grad.detach().clone() for n, p in ff.named_parameters()}))
+            return outs
+
+        a, b = run(True), run(False)
+        for (ya, dxa, ga), (yb, dxb, gb) in zip(a, b):
+            assert torch.equal(ya, yb), float((ya - yb).abs().max())
+            assert torch.allclose(dxa, dxb, atol=3e-2 * float(dxb.abs().max()), rtol=3e-2), float((dxa - dxb).abs().max())
+            for n in ga:
+                # out_layer: both paths contract the same gradient over the same rows (f32 sums in another tile order); in_layer: its
+                # incoming gradient is the out_layer's data gradient, which the two paths round differently (above)
+                tol = 2e-3 if n.startswith("out_layer") else 1.5e-2
+                assert torch.allclose(ga[n], gb[n], atol=tol * float(gb[n].abs().max()) + 1e-6, rtol=tol), (n, float((ga[n] - gb[n]).abs().max()))
+        assert torch.equal(a[0][0], a[1][0])  # same seed, same step -> the same result both times
+    finally:
+        Fn.GradSinks.clear()
+        Fn.set_compute_dtype(None)
