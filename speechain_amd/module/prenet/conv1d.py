@@ -32,8 +32,7 @@ class Conv1dEv(nn.Module):
 
     def forward_btc(self, x: torch.Tensor, drop_p: float = 0.0, residual=None) -> torch.Tensor:
         """(B, T, C_in) -> (B, T, C_out): the layout the HIP path works in."""
-        return Fn.linear(shifted_cat(Fn.to_compute(x), self.kernel_size), [self.conv_lyr.weight], [self.conv_lyr.bias], drop_p=drop_p,
-                         residual=residual)
+        return Fn.conv_linear(Fn.to_compute(x), self.conv_lyr.weight, self.conv_lyr.bias, None, drop_p, residual)
 
     def forward(self, feat: torch.Tensor) -> torch.Tensor:
         """The reference's layout: (batch, feat_dim, feat_maxlen) -> (batch, out_channels, feat_maxlen)."""

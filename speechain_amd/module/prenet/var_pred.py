@@ -75,7 +75,7 @@ class Conv1dVarPredictor(Module):
         i = 0
         while i < len(mods):
             conv, ln = mods[i], mods[i + 2]
-            x = Fn.linear_act(shifted_cat(x, conv.kernel_size), conv.conv_lyr.weight, conv.conv_lyr.bias, "ReLU", 0.0)
+            x = Fn.conv_linear(x, conv.conv_lyr.weight, conv.conv_lyr.bias, "ReLU", 0.0)  # (im2col-free when training with gradient sinks)
             x = Fn.layer_norm(x, ln.weight, ln.bias, ln.eps)
             i += 3
             if i < len(mods) and isinstance(mods[i], torch.nn.Dropout):
