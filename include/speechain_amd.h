@@ -388,11 +388,13 @@ int sc_cast_transpose(int dtype_out, const float* in, void* out, int R, int C, l
 
 /* Batched refresh of compute-dtype weight copies in ONE launch.  `desc` is a device array of n_desc records
  *   struct sc_cast_desc { const float* src; void* dst; void* dst_t; int rows, cols; long long ld_dst, ld_dst_t; int tile0, tiles_x;
- *                         int conv_k, pad; };
+ *                         int conv_k, tr_rev; };
  * (64 bytes): record i owns tiles [tile0_i, tile0_{i+1}) of 64 x 64 elements of its (rows, cols) float32 matrix,
  * tiles_x = ceil(cols/64); each tile is written as `dtype_out` to dst (row stride ld_dst) and/or transposed to dst_t
  * (row stride ld_dst_t); null pointers are skipped.  total_tiles = sum of all records' tiles.  conv_k > 1: src is an nn.Conv1d weight
- * (rows, cols / conv_k, conv_k) (prenet/conv1d.py:99-108) read as the GEMM matrix of the 'same' convolution, column = tap * C_in + channel. */
+ * (rows, cols / conv_k, conv_k) (prenet/conv1d.py:99-108) read as the GEMM matrix of the 'same' convolution, column = tap * C_in + channel;
+ * tr_rev = 1: row (tap, channel) of the transposed copy goes to row channel * conv_k + (conv_k - 1 - tap) (the data-gradient matrix of
+ * the im2col-free convolution, functional._ConvLinear). */
 int sc_cast_weights(int dtype_out, const void* desc, int n_desc, int total_tiles, hipStream_t stream);
 
 /* y = dropout(x * xscale + table[t] * (*alpha)) for x (B, T, D), table (>= T, D) f32 (pos_enc.py:168-182). */

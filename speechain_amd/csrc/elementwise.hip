@@ -114,7 +114,9 @@ struct CastDesc {
   int rows, cols;
   long long ld_dst, ld_dst_t;
   int tile0, tiles_x;
-  int conv_k, pad_;  // conv_k > 1: src is a Conv1d weight (rows, cols / conv_k, conv_k); column c of the GEMM matrix = tap c / C, channel c % C
+  int conv_k, tr_rev;  // conv_k > 1: src is a Conv1d weight (rows, cols / conv_k, conv_k); column c of the GEMM matrix = tap c / C, channel c % C
+                       // tr_rev = 1 (with conv_k > 1): row (tap, channel) of the transposed copy is stored at row channel * conv_k + (conv_k - 1 - tap)
+                       // -- the (C, k N) matrix [channel][j N + out] = w[out][channel][k - 1 - j] of the im2col-free Conv1d's data gradient
 };
 
 // 64 x 64 tiles, 256 threads: 16-byte f32 reads (4 columns per thread, 16 rows per pass), 8-byte bf16 stores; the transposed copy goes
@@ -177,7 +179,12 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(const CastDesc* desc,
   for (int i = 0; i < 4; ++i) {
     const int cl = ty + 16 * i, c = c0 + cl, r = r0 + 4 * tx;  // destination row c, 4 consecutive source rows
     if (c >= d.cols) continue;
-    const long long o = (long long)c * d.ld_dst_t + r;
+    long long drow = c;
+    if (d.tr_rev && d.conv_k > 1) {
+      const int C = d.cols / d.conv_k;
+      drow = (long long)(c % C) * d.conv_k + (d.conv_k - 1 - c / C);
+    }
+    const long long o = drow * d.ld_dst_t + r;
     if (sizeof(TO) == 2 && r + 4 <= d.rows && (d.ld_dst_t & 3) == 0 && ((uintptr_t)d.dst_t & 7) == 0) {
       uint2 w;
       w.x = sc_f32_to_bf16(tile[4 * tx][cl]) | ((unsigned)sc_f32_to_bf16(tile[4 * tx + 1][cl]) << 16);

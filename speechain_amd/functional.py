@@ -214,6 +214,24 @@ class _WeightCache:
             self._put(key, params, buf)
         return buf
 
+    def conv_dgrad(self, w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """(C, k N) compute-dtype matrix [channel][j N + out] = w[out][channel][k - 1 - j] of an nn.Conv1d weight (N, C, k): the operand of the
+        im2col-free convolution's data gradient (`_ConvLinear.backward`).  Kept current by `refresh()` like the other copies."""
+        cacheable = w.is_leaf
+        key = ((id(w),), dtype, "D")
+        hit = self._lookup(key, [w]) if cacheable else None
+        if hit is not None and hit[0] == self._ver([w]):
+            return hit[1]
+        N, C, k = w.shape
+        src = w.detach().permute(1, 2, 0).flip(1).reshape(C, k * N).to(dtype)  # [c][j][o] = w[o][c][k - 1 - j]
+        if hit is not None:
+            buf = hit[1].copy_(src)  # in place: a captured graph may hold the buffer's address
+        else:
+            buf = src.contiguous()
+        if cacheable:
+            self._put(key, [w], buf)
+        return buf
+
     def vector(self, params: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
         """float32 concatenation of bias vectors (None if there is no bias).  The biases of one fused call are all present or all
         absent (the drop-in modules never mix them; `linear` checks)."""
@@ -253,7 +271,7 @@ class _WeightCache:
                 recs, tile0 = [], 0
                 for k, v in ents:
                     buf, params = v[1], [r() for r in v[2]]
-                    transposed = len(k) == 3 and k[2] == "T"
+                    transposed = len(k) == 3 and k[2] in ("T", "D")  # ("D": the transposed copy with its (tap, channel) rows re-ordered)
                     r = 0
                     for p in params:
                         assert p.is_contiguous() and p.dtype == torch.float32
@@ -264,12 +282,13 @@ class _WeightCache:
                         else:
                             rows, cols = p.size(0), p.numel() // p.size(0)
                             if transposed:
-                                rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, buf.size(1), tile0, (cols + 63) // 64)
+                                ldt = rows if k[2] == "D" else buf.size(1)  # ("D" is stored as (C, k N): its (C k, N) rows are N long)
+                                rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, ldt, tile0, (cols + 63) // 64)
                             else:
                                 rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 63) // 64)
                             r += rows
                         conv_k = p.size(2) if (p.dim() == 3 and k[1] != "vec") else 1
-                        recs.append(struct.pack("<QQQiiqqiiii", *rec, conv_k, 0))
+                        recs.append(struct.pack("<QQQiiqqiiii", *rec, conv_k, 1 if (len(k) == 3 and k[2] == "D") else 0))
                         tile0 += ((cols + 63) // 64) * ((rows + 63) // 64)
                 dev = ents[0][1][1].device
                 cur = (sig, torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev), len(recs), tile0)
@@ -832,8 +851,7 @@ class _ConvLinear(torch.autograd.Function):
         dW, db = wgrad(BF16, dzv, x2v, [w], bias=True, bias_params=bp) if bp else (wgrad(BF16, dzv, x2v, [w]), None)
         dx = None
         if ctx.needs_input_grad[0]:
-            Wt = weights.fused_t([w], dz.dtype).view(k, C, N)  # [tap][channel][out]
-            D = torch.stack([Wt[k - 1 - j] for j in range(k)], dim=1).view(C, k * N)  # [channel][j * N + out] = w[out][channel][k - 1 - j]
+            D = weights.conv_dgrad(w, dz.dtype)  # (C, k N): [channel][j * N + out] = w[out][channel][k - 1 - j]
             dx = torch.empty(M, C, dtype=dz.dtype, device=dz.device)
             gemm(BF16, _p(dzp), _p(D), _p(dx), T, C, k * N, N, k * N, C, nb=(B, 1), sA=(Tp * N, 0), sC=(T * C, 0))
             dx = dx.view(B, T, C)

@@ -215,6 +215,10 @@ def test_conv_feed_forward_without_im2col_equals_the_im2col_path(monkeypatch, T,
             red = GradBucketReducer(ff.parameters(), bucket_mb=0.25)
             outs = []
             for step in range(2):  # twice: no stale slots, no double counting
+                if step == 1:  # a raw in-place update (as FusedAdam makes) + the batched refresh of every cached weight copy
+                    for p in ff.parameters():
+                        p.data.mul_(1.05)
+                    Fn.weights.refresh()
                 Fn.DropoutState.reset(1234)
                 Fn.DropoutState.advance()
                 red.zero_grad()
@@ -235,7 +239,7 @@ def test_conv_feed_forward_without_im2col_equals_the_im2col_path(monkeypatch, T,
                 # incoming gradient is the out_layer's data gradient, which the two paths round differently (above)
                 tol = 2e-3 if n.startswith("out_layer") else 1.5e-2
                 assert torch.allclose(ga[n], gb[n], atol=tol * float(gb[n].abs().max()) + 1e-6, rtol=tol), (n, float((ga[n] - gb[n]).abs().max()))
-        assert torch.equal(a[0][0], a[1][0])  # same seed, same step -> the same result both times
+        assert not torch.equal(a[0][0], a[1][0])  # (the second step ran on the updated weights)
     finally:
         Fn.GradSinks.clear()
         Fn.set_compute_dtype(None)
