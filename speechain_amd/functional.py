@@ -840,14 +840,8 @@ class _ConvLinear(torch.autograd.Function):
         else:
             dz = _masked_grad(dy2, drop_p, seed, off)
         dzp = _pad_rows(dz.view(B, T, N), r)
-        tokens = (B * Tp + 31) // 32 * 32
-        # window i of xp (rows i .. i + k - 1) belongs to the output position whose gradient sits at row i + r of dzp; the windows that
-        # straddle two utterances meet zero rows there
-        x2v = xp.as_strided((tokens, k * C), (C, 1))
-        dzv = dzp.as_strided((tokens, N), (N, 1), r * N)
         bp = ctx.bias_params
-        if not (GradSinks.peek([w]) and (not bp or GradSinks.peek(bp))):
-            x2v = x2v.contiguous()  # (not the configuration this path is for: the immediate weight-gradient kernels want distinct rows)
+        dzv, x2v = _conv_views(xp, dzp, B, Tp, r, k * C, C, N, [w] + bp)
         dW, db = wgrad(BF16, dzv, x2v, [w], bias=True, bias_params=bp) if bp else (wgrad(BF16, dzv, x2v, [w]), None)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -856,6 +850,98 @@ class _ConvLinear(torch.autograd.Function):
             gemm(BF16, _p(dzp), _p(D), _p(dx), T, C, k * N, N, k * N, C, nb=(B, 1), sA=(Tp * N, 0), sC=(T * C, 0))
             dx = dx.view(B, T, C)
         return dx, (dy if has_res else None), dW.view_as(w), db, None, None
+
+
+def _conv_views(img: torch.Tensor, gimg: torch.Tensor, B: int, Tp: int, r: int, kc: int, c: int, n: int, params: Sequence[torch.Tensor]):
+    """Operands of the weight gradient over the padded images (see `_ConvLinear.backward`): window i of `img` (rows i .. i + k - 1) belongs to
+    the output position whose gradient sits at row i + r of `gimg`; windows that straddle two utterances meet zero rows there."""
+    tokens = (B * Tp + 31) // 32 * 32
+    x2v = img.as_strided((tokens, kc), (c, 1))
+    dzv = gimg.as_strided((tokens, n), (n, 1), r * n)
+    if not all(GradSinks.peek([p]) for p in params):
+        x2v = x2v.contiguous()  # (not the configuration this path is for: the immediate weight-gradient kernels want distinct rows)
+    return dzv, x2v
+
+
+class _ConvFFN(torch.autograd.Function):
+    """The conv-type position-wise feed-forward (speechain/module/transformer/feed_forward.py:71-95: Conv1d -> activation -> dropout ->
+    Conv1d -> dropout [+ residual]) on the im2col-free products of `_ConvLinear`, with what `_FFN` does for the linear type: the first
+    product stores act'(pre) x dropout factor next to the hidden activation, and the second convolution's data-gradient product
+    multiplies by it in its epilogue -- no separate activation-backward launch."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, act, p_h, p_res):
+        require_gpu(x, "conv feed-forward")
+        x = x if x.is_contiguous() else x.contiguous()
+        B, T, C = x.shape
+        Fd, _, k1 = w1.shape
+        C2, _, k2 = w2.shape
+        r1, r2 = (k1 - 1) // 2, (k2 - 1) // 2
+        M = B * T
+        xp = _pad_rows(x, r1)
+        W1, W2 = weights.fused([w1], x.dtype), weights.fused([w2], x.dtype)
+        fac = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
+        h = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
+        s1, o1 = DropoutState.next(M * Fd, x.device) if p_h > 0 else (0, 0)
+        gemm(BF16, _p(xp), _p(W1), _p(h), T, Fd, k1 * C, C, k1 * C, Fd, nb=(B, 1), sA=((T + 2 * r1) * C, 0), sC=(T * Fd, 0),
+             bias=b1.detach() if b1 is not None else None, act=act | 0x100, pre_out=_p(fac), drop=(p_h, s1, o1))
+        hp = _pad_rows(h.view(B, T, Fd), r2)
+        del h
+        y = torch.empty(M, C2, dtype=x.dtype, device=x.device)
+        s2, o2 = DropoutState.next(M * C2, x.device) if p_res > 0 else (0, 0)
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(M, C2)
+            res2 = res2 if res2.is_contiguous() else res2.contiguous()
+        gemm(BF16, _p(hp), _p(W2), _p(y), T, C2, k2 * Fd, Fd, k2 * Fd, C2, nb=(B, 1), sA=((T + 2 * r2) * Fd, 0), sC=(T * C2, 0),
+             bias=b2.detach() if b2 is not None else None, aux=_p(res2), ldaux=C2, aux_mode=1 if res2 is not None else 0,
+             drop=(p_res, s2, o2))
+        ctx.save_for_backward(xp, fac, hp, w1, w2)
+        ctx.bias_params = [[b1] if b1 is not None else [], [b2] if b2 is not None else []]
+        ctx.meta = (B, T, C, Fd, C2, k1, k2, p_res, s2, o2, residual is not None)
+        _MaskedGrad.note_site(y, p_res, s2, o2)
+        return y.view(B, T, C2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, fac, hp, w1, w2 = ctx.saved_tensors
+        B, T, C, Fd, C2, k1, k2, p_res, s2, o2, has_res = ctx.meta
+        r1, r2 = (k1 - 1) // 2, (k2 - 1) // 2
+        M = B * T
+        bp1, bp2 = ctx.bias_params
+        dy2 = dy.reshape(M, C2)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dz2p = _pad_rows(_masked_grad(dy2, p_res, s2, o2).view(B, T, C2), r2)
+        dzv, x2v = _conv_views(hp, dz2p, B, T + 2 * r2, r2, k2 * Fd, Fd, C2, [w2] + bp2)
+        dW2, db2 = wgrad(BF16, dzv, x2v, [w2], bias=True, bias_params=bp2) if bp2 else (wgrad(BF16, dzv, x2v, [w2]), None)
+        # dz1 = (second convolution's data gradient) * [act'(pre) * keepmask_h / (1 - p_h)]: the bracket is `fac`
+        dz1 = torch.empty(M, Fd, dtype=dy2.dtype, device=dy2.device)
+        gemm(BF16, _p(dz2p), _p(weights.conv_dgrad(w2, dy2.dtype)), _p(dz1), T, Fd, k2 * C2, C2, k2 * C2, Fd, nb=(B, 1),
+             sA=((T + 2 * r2) * C2, 0), sC=(T * Fd, 0), aux=_p(fac), ldaux=Fd, aux_mode=3)
+        dz1p = _pad_rows(dz1.view(B, T, Fd), r1)
+        del dz1
+        dzv, x2v = _conv_views(xp, dz1p, B, T + 2 * r1, r1, k1 * C, C, Fd, [w1] + bp1)
+        dW1, db1 = wgrad(BF16, dzv, x2v, [w1], bias=True, bias_params=bp1) if bp1 else (wgrad(BF16, dzv, x2v, [w1]), None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, C, dtype=dy2.dtype, device=dy2.device)
+            gemm(BF16, _p(dz1p), _p(weights.conv_dgrad(w1, dy2.dtype)), _p(dx), T, C, k1 * Fd, Fd, k1 * Fd, C, nb=(B, 1),
+                 sA=((T + 2 * r1) * Fd, 0), sC=(T * C, 0))
+            dx = dx.view(B, T, C)
+        return dx, (dy if has_res else None), dW1.view_as(w1), db1, dW2.view_as(w2), db2, None, None, None
+
+
+def conv_ffn(x: torch.Tensor, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor], activation: str,
+             p_hidden: float = 0.0, p_res: float = 0.0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Conv1d -> activation -> dropout -> Conv1d -> dropout [+ residual] over (B, T, C) with nn.Conv1d weights: `_ConvFFN` when both
+    convolutions qualify for the im2col-free path, else two `conv_linear` calls.  Same forward arithmetic either way."""
+    if activation not in ACT or not ACT[activation]:
+        raise NotImplementedError(f"speechain_amd conv feed-forward implements ReLU and GELU, got {activation}")
+    if conv_direct_ok(x, w1, b1) and w2.dim() == 3 and w2.size(2) > 1 and w2.size(2) % 2 == 1 and w2.size(1) == w1.size(0) and \
+            w2.size(0) % 8 == 0 and w2.is_leaf and id(w2) in GradSinks.table and (b2 is None or id(b2) in GradSinks.table):
+        return _ConvFFN.apply(x, residual, w1, b1, w2, b2, ACT[activation], float(p_hidden), float(p_res))
+    h = conv_linear(x, w1, b1, activation, p_hidden)
+    return conv_linear(h, w2, b2, None, p_res, residual)
 
 
 def conv_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], activation: Optional[str] = None, drop_p: float = 0.0,

@@ -46,7 +46,7 @@ class PositionwiseFeedForward(Module):
         cin, cout = self.in_layer, self.out_layer
         # (the Conv1d weights go in as they are, (out, in, k): functional reads them as the (out, k * in) matrices of these products and
         # writes their gradients back in the weights' own layout -- cached casts, gradient-bucket slots, the grouped wgrad launch)
-        # (Fn.conv_linear: with gradient sinks registered -- the training step -- one product over overlapping rows of a zero-padded image,
-        #  no im2col / col2im; otherwise shifted_cat + linear.  Same arithmetic, bit for bit.)
-        h = Fn.conv_linear(x, cin.conv_lyr.weight, cin.conv_lyr.bias, self.activation_name, p)
-        return Fn.conv_linear(h, cout.conv_lyr.weight, cout.conv_lyr.bias, None, _res_drop, res)
+        # (Fn.conv_ffn: with gradient sinks registered -- the training step -- products over overlapping rows of zero-padded images, no
+        #  im2col / col2im / activation-backward launches; otherwise shifted_cat + linear.  Same forward arithmetic, bit for bit.)
+        return Fn.conv_ffn(x, cin.conv_lyr.weight, cin.conv_lyr.bias, cout.conv_lyr.weight, cout.conv_lyr.bias, self.activation_name, p,
+                           _res_drop, res)
