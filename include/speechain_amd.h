@@ -379,6 +379,9 @@ int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n,
  * zero rows behind the last utterance.  With it a 'same' Conv1d (speechain/module/prenet/conv1d.py:Conv1dEv, the conv-type feed-forward of
  * speechain/module/transformer/feed_forward.py:71-95) is ONE sc_gemm over overlapping rows (lda = C < K = k C) instead of im2col + GEMM. */
 int sc_pad_rows(const void* x, int B, int T, int C, int r, void* out, long long rows_total, hipStream_t stream);
+/* Only the zero rows of that image (2 r per utterance + the tail): for a producer that writes the data rows itself -- an sc_gemm with
+ * C = out + r * C_row, batch stride sC1 = (T + 2 r) * C_row. */
+int sc_zero_pad_rows(int B, int T, int C, int r, void* out, long long rows_total, hipStream_t stream);
 /* dW (V, D) f32 of out = table[ids] from dy (N, D; row stride ld): autograd of the token embedding (speechain/module/prenet/embed.py:55-66).
  * Deterministic, no atomics (the first position holding an id sums all of that id's rows in position order); the row of padding_idx
  * (nn.Embedding's) stays zero; pass a negative padding_idx for none.  ids in [0, V). */

@@ -104,6 +104,26 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const uint4* x, int B, in
   }
 }
 
+// (see sc_zero_pad_rows) the pad rows of a padded image only: 2 r rows per utterance + the rows behind the last utterance
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(int B, int T, int C8, int r, uint4* out, long long rows_total) {
+  const int Tp = T + 2 * r;
+  const long long npad = (long long)B * 2 * r + (rows_total - (long long)B * Tp);
+  const long long n = npad * C8, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long pr = i / C8;
+    const int c = (int)(i - pr * C8);
+    long long row;
+    if (pr < (long long)B * 2 * r) {
+      const long long b = pr / (2 * r);
+      const int j = (int)(pr - b * 2 * r);
+      row = b * Tp + (j < r ? j : T + j);
+    } else {
+      row = (long long)B * Tp + (pr - (long long)B * 2 * r);
+    }
+    out[row * C8 + c] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 // One launch refreshing many compute-dtype weight copies: descriptor d covers tiles [tile0, next.tile0) of a (rows, cols)
 // f32 matrix; every 32 x 32 tile is written to dst (same layout, row stride ld_dst) and/or dst_t (transposed, row stride
 // ld_dst_t).  Layout of sc_cast_desc: include/speechain_amd.h.
@@ -285,6 +305,19 @@ SC_API int sc_pad_rows(const void* x, int B, int T, int C, int r, void* out, lon
   const long long n = rows_total * (C / 8);
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const uint4*)x, B, T, C / 8, r, (uint4*)out, n);
   SC_LAUNCH_CHECK("pad_rows_kernel");
+  return SC_OK;
+}
+
+// The zero rows of the image sc_pad_rows describes, and nothing else: for a producer (a GEMM with batch stride (T + 2 r) C and its output
+// pointer r rows in) that writes the data rows itself.
+SC_API int sc_zero_pad_rows(int B, int T, int C, int r, void* out, long long rows_total, hipStream_t stream) {
+  SC_CHECK_ARG(out && B >= 1 && T >= 1 && C >= 8 && C % 8 == 0 && r >= 0 && rows_total >= (long long)B * (T + 2 * r) &&
+                   (uintptr_t)out % 16 == 0,
+               "sc_zero_pad_rows: bad arguments (B=%d T=%d C=%d r=%d rows=%lld; bf16, C %% 8 == 0, 16-byte aligned)", B, T, C, r, rows_total);
+  const long long n = ((long long)B * 2 * r + (rows_total - (long long)B * (T + 2 * r))) * (C / 8);
+  if (n == 0) return SC_OK;
+  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(grid_for(n)), dim3(256), 0, stream, B, T, C / 8, r, (uint4*)out, rows_total);
+  SC_LAUNCH_CHECK("zero_pad_rows_kernel");
   return SC_OK;
 }
 

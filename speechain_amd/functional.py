@@ -782,6 +782,15 @@ def _pad_rows(x3: torch.Tensor, r: int) -> torch.Tensor:
     return out
 
 
+def _padded_empty(B: int, T: int, C: int, r: int, like: torch.Tensor) -> torch.Tensor:
+    """The image of `_pad_rows` with its zero rows written and its data rows left to a GEMM (output pointer r rows in, batch stride
+    (T + 2 r) C)."""
+    rows = (B * (T + 2 * r) + 31) // 32 * 32 + 32
+    out = torch.empty(rows, C, dtype=like.dtype, device=like.device)
+    lib.call("sc_zero_pad_rows", B, T, C, r, _p(out), rows, stream())
+    return out
+
+
 def conv_direct_ok(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> bool:
     """The im2col-free path serves the training configuration it was built for: bf16 compute on the GPU, channel counts in whole 16-byte
     chunks, odd taps, and the weight's (and bias') gradient written into bucket slots by the grouped launch (GradSinks registered) --
@@ -880,13 +889,22 @@ class _ConvFFN(torch.autograd.Function):
         M = B * T
         xp = _pad_rows(x, r1)
         W1, W2 = weights.fused([w1], x.dtype), weights.fused([w2], x.dtype)
-        fac = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
-        h = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
         s1, o1 = DropoutState.next(M * Fd, x.device) if p_h > 0 else (0, 0)
-        gemm(BF16, _p(xp), _p(W1), _p(h), T, Fd, k1 * C, C, k1 * C, Fd, nb=(B, 1), sA=((T + 2 * r1) * C, 0), sC=(T * Fd, 0),
-             bias=b1.detach() if b1 is not None else None, act=act | 0x100, pre_out=_p(fac), drop=(p_h, s1, o1))
-        hp = _pad_rows(h.view(B, T, Fd), r2)
-        del h
+        if r1 == r2:
+            # the first product writes the hidden activation straight into the second convolution's padded image (and the factor into an
+            # image of the same geometry: the epilogue addresses both through the output's batch stride) -- no pad pass over (M, Fd)
+            hp = _padded_empty(B, T, Fd, r2, x)
+            fac = torch.empty_like(hp)
+            gemm(BF16, _p(xp), _p(W1), _p(hp, r2 * Fd), T, Fd, k1 * C, C, k1 * C, Fd, nb=(B, 1), sA=((T + 2 * r1) * C, 0),
+                 sC=((T + 2 * r2) * Fd, 0), bias=b1.detach() if b1 is not None else None, act=act | 0x100, pre_out=_p(fac, r2 * Fd),
+                 drop=(p_h, s1, o1))
+        else:
+            fac = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
+            h = torch.empty(M, Fd, dtype=x.dtype, device=x.device)
+            gemm(BF16, _p(xp), _p(W1), _p(h), T, Fd, k1 * C, C, k1 * C, Fd, nb=(B, 1), sA=((T + 2 * r1) * C, 0), sC=(T * Fd, 0),
+                 bias=b1.detach() if b1 is not None else None, act=act | 0x100, pre_out=_p(fac), drop=(p_h, s1, o1))
+            hp = _pad_rows(h.view(B, T, Fd), r2)
+            del h
         y = torch.empty(M, C2, dtype=x.dtype, device=x.device)
         s2, o2 = DropoutState.next(M * C2, x.device) if p_res > 0 else (0, 0)
         res2 = None
@@ -915,11 +933,16 @@ class _ConvFFN(torch.autograd.Function):
         dzv, x2v = _conv_views(hp, dz2p, B, T + 2 * r2, r2, k2 * Fd, Fd, C2, [w2] + bp2)
         dW2, db2 = wgrad(BF16, dzv, x2v, [w2], bias=True, bias_params=bp2) if bp2 else (wgrad(BF16, dzv, x2v, [w2]), None)
         # dz1 = (second convolution's data gradient) * [act'(pre) * keepmask_h / (1 - p_h)]: the bracket is `fac`
-        dz1 = torch.empty(M, Fd, dtype=dy2.dtype, device=dy2.device)
-        gemm(BF16, _p(dz2p), _p(weights.conv_dgrad(w2, dy2.dtype)), _p(dz1), T, Fd, k2 * C2, C2, k2 * C2, Fd, nb=(B, 1),
-             sA=((T + 2 * r2) * C2, 0), sC=(T * Fd, 0), aux=_p(fac), ldaux=Fd, aux_mode=3)
-        dz1p = _pad_rows(dz1.view(B, T, Fd), r1)
-        del dz1
+        if r1 == r2:  # (fac is an image of the geometry dz1p gets: the product writes dz1p's data rows directly)
+            dz1p = _padded_empty(B, T, Fd, r1, dy2)
+            gemm(BF16, _p(dz2p), _p(weights.conv_dgrad(w2, dy2.dtype)), _p(dz1p, r1 * Fd), T, Fd, k2 * C2, C2, k2 * C2, Fd, nb=(B, 1),
+                 sA=((T + 2 * r2) * C2, 0), sC=((T + 2 * r1) * Fd, 0), aux=_p(fac, r1 * Fd), ldaux=Fd, aux_mode=3)
+        else:
+            dz1 = torch.empty(M, Fd, dtype=dy2.dtype, device=dy2.device)
+            gemm(BF16, _p(dz2p), _p(weights.conv_dgrad(w2, dy2.dtype)), _p(dz1), T, Fd, k2 * C2, C2, k2 * C2, Fd, nb=(B, 1),
+                 sA=((T + 2 * r2) * C2, 0), sC=(T * Fd, 0), aux=_p(fac), ldaux=Fd, aux_mode=3)
+            dz1p = _pad_rows(dz1.view(B, T, Fd), r1)
+            del dz1
         dzv, x2v = _conv_views(xp, dz1p, B, T + 2 * r1, r1, k1 * C, C, Fd, [w1] + bp1)
         dW1, db1 = wgrad(BF16, dzv, x2v, [w1], bias=True, bias_params=bp1) if bp1 else (wgrad(BF16, dzv, x2v, [w1]), None)
         dx = None
