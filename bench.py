@@ -424,8 +424,9 @@ class ASRTrainStepWorkload:
         achieved = df / (dt * 1e-3) / 1e12 if dt > 0 else 0.0
         return {"bound": "mfma", "kernel": lib.load().sc_gemm_kernel_name(dom_id).decode(), "achieved": round(achieved, 2),
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5),
-                "traffic": pmc_traffic(lib.load().sc_gemm_kernel_name(dom_id).decode()),
-                "mfma_busy_pmc": pmc_mfma_busy(lib.load().sc_gemm_kernel_name(dom_id).decode()),
+                # (the committed PMC passes are of the ASR step: its per-launch averages describe that step's mix of shapes only)
+                "traffic": pmc_traffic(lib.load().sc_gemm_kernel_name(dom_id).decode()) if isinstance(self, ASRTrainStepWorkload) else None,
+                "mfma_busy_pmc": pmc_mfma_busy(lib.load().sc_gemm_kernel_name(dom_id).decode()) if isinstance(self, ASRTrainStepWorkload) else None,
                 "launches_timed": dc, "avg_launch_ms": round(dt / max(dc, 1), 5), "kernel_flops_timed": df,
                 "all_gemm_launches": {"achieved": round(agg, 2), "frac": round(agg / MFMA_BF16_PEAK_TFLOPS, 5), "launches_timed": n,
                                       "avg_launch_ms": round(ms / max(n, 1), 5), "gemm_flops_timed": self.flops},
