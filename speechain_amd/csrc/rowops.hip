@@ -463,12 +463,22 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(SoftmaxArgs p) {
     const int k0 = 8 * (lane + 64 * c);
     if (k0 < p.ld) {
       ln_unpack8(*reinterpret_cast<const uint4*>(S + base + k0), v[c]);
+      unsigned long long mb = ~0ull;  // the 8 mask bytes of this chunk (a byte != 0 keeps the key)
+      if (mrow) {
+        if ((((uintptr_t)(mrow + k0)) & 7) == 0 && k0 + 8 <= p.Tk) {
+          mb = *reinterpret_cast<const unsigned long long*>(mrow + k0);
+        } else {
+          mb = 0ull;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + e < p.Tk) mb |= (unsigned long long)mrow[k0 + e] << (8 * e);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = k0 + e;
-        bool ok = k < p.Tk;
-        if (ok && mrow) ok = mrow[k] != 0;
-        if (ok && p.causal) ok = k <= q;
+        bool ok = k < p.Tk && ((mb >> (8 * e)) & 0xFFull) != 0;
+        if (p.causal) ok = ok && k <= q;
         v[c][e] = ok ? v[c][e] : -INFINITY;
         mx = fmaxf(mx, v[c][e]);
       }
@@ -479,11 +489,14 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(SoftmaxArgs p) {
   }
   mx = sc_wave_max(mx);
   float s = 0.f;
+  const float mxl = mx * 1.44269504088896341f;
 #pragma unroll
   for (int c = 0; c < NV; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      v[c][e] = (v[c][e] == -INFINITY) ? 0.f : expf(v[c][e] - mx);
+      // exp(v - mx) as one v_exp_f32 on (v log2 e - mx log2 e); a masked key (-inf) gives exactly 0, a fully masked row (mx = -inf) is
+      // caught below
+      v[c][e] = (v[c][e] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(v[c][e], 1.44269504088896341f, -mxl));
       s += v[c][e];
     }
   s = sc_wave_sum(s);
@@ -502,12 +515,17 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(SoftmaxArgs p) {
     *reinterpret_cast<uint4*>((unsigned short*)p.P + base + k0) = packed;
     if (p.Pd) {
       float d[8];
-      ln_unpack8(packed, d);
+      const unsigned long long idx0 = p.offset + (unsigned long long)(base + k0);
+      unsigned hsh = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        // (from the value before rounding, as the element-per-lane kernel does)
+        // (from the value before rounding, as the element-per-lane kernel does; one hash serves the two elements of a pair)
         d[e] = pr[e];
-        if (p.drop_p > 0.f) d[e] = sc_dropped(seed, p.offset + base + k0 + e, thr) ? 0.f : pr[e] * keep;
+        if (p.drop_p > 0.f) {
+          const unsigned long long idx = idx0 + e;
+          if (e == 0 || (idx & 1) == 0) hsh = sc_rand_pair(seed, idx >> 1);
+          d[e] = (((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr) ? 0.f : pr[e] * keep;
+        }
       }
       *reinterpret_cast<uint4*>((unsigned short*)p.Pd + base + k0) = ln_pack8(d);
     }
@@ -533,10 +551,16 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const unsigned sho
     if (k0 < ld) {
       ln_unpack8(*reinterpret_cast<const uint4*>(P + base + k0), pr[c]);
       ln_unpack8(*reinterpret_cast<const uint4*>(dPd + base + k0), dp[c]);
+      const unsigned long long idx0 = offset + (unsigned long long)(base + k0);
+      unsigned hsh = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (k0 + e < Tk) {
-          if (drop_p > 0.f) dp[c][e] = sc_dropped(seed, offset + base + k0 + e, thr) ? 0.f : dp[c][e] * keep;
+          if (drop_p > 0.f) {
+            const unsigned long long idx = idx0 + e;
+            if (e == 0 || (idx & 1) == 0) hsh = sc_rand_pair(seed, idx >> 1);
+            dp[c][e] = (((hsh >> (16u * (unsigned)(idx & 1))) & 0xFFFFu) < thr) ? 0.f : dp[c][e] * keep;
+          }
           dot += dp[c][e] * pr[c][e];
         } else {
           pr[c][e] = dp[c][e] = 0.f;
