@@ -161,7 +161,11 @@ class ASRTrainStepWorkload:
         grad_pg = None
         if distributed and os.environ.get("BENCH_GRAD_PG", "1") == "1":
             import torch.distributed as dist
-            grad_pg = dist.new_group(backend="nccl")
+            try:
+                grad_pg = dist.new_group(backend="nccl")
+            except Exception as e:  # (a second communicator is an optimisation, never a reason to lose the run)
+                print(f"bench: dist.new_group failed ({e}); gradient buckets stay on the default process group", file=sys.stderr)
+                grad_pg = None
         self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, process_group=grad_pg, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
         self.lr = torch.tensor([2e-3], device=device)
