@@ -340,6 +340,10 @@ int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev
 /* Row-wise top-K of a (R, L) f32 matrix, row stride ld: vals / idx (R, K) in descending order, ties by the lower index; K <= 64.
  * The candidate selection of a beam-search step (speechain/infer_func/beam_search.py:419-421: torch.topk over (batch, beam * vocab)). */
 int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream);
+/* Second stage of the same selection over G groups of `parts` consecutive rows (beam_search.py:401-410 takes the top 2 * beam of a
+ * sentence's beam * vocabulary candidates): from sc_topk_rows' per-row results (G * parts, K) to (G, K) with idx = row-in-group * L +
+ * column -- identical to sc_topk_rows on the (G, parts * L) view, ties included.  parts * K <= 1024. */
+int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, int K, int L, float* vals, long long* idx, hipStream_t stream);
 
 /* Candidate scores of a beam-search step (speechain/infer_func/beam_search.py:334-345,401-410) in one pass over the token head's logits:
  *   cand[n][v] = (1 - ctc_weight) * log_softmax(logits[n] / temperature)[v] + ctc_weight * (psi[n][v] - psi_prev[n]) + beam_score[n],

@@ -615,7 +615,42 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long lo
   }
 }
 
+// Second stage of a two-stage top-K over G groups of `parts` rows each (see sc_topk_merge): candidate j of part p sits at column p K + j.
+// One workgroup per group, one thread per candidate; a candidate's rank is the number of candidates that beat it (higher key, or the same
+// key at a lower column: the parts are in index order and each part's candidates are sorted with ties by the lower index, so column order
+// IS index order among equal keys).
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const float* vals1, const long long* idx1, int parts, int K, int L, float* vals,
+                                                          long long* idx) {
+  __shared__ unsigned key[1024];
+  const int n = parts * K, tid = threadIdx.x;
+  const long long base = (long long)blockIdx.x * n;
+  if (tid < n) key[tid] = topk_key(vals1[base + tid]);
+  __syncthreads();
+  if (tid >= n) return;
+  const unsigned k = key[tid];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) rank += (key[j] > k) || (key[j] == k && j < tid);
+  if (rank < K) {
+    vals[(long long)blockIdx.x * K + rank] = vals1[base + tid];
+    idx[(long long)blockIdx.x * K + rank] = (long long)(tid / K) * L + idx1[base + tid];
+  }
+}
+
 }  // namespace
+
+// The K largest of every GROUP of `parts` consecutive rows of length L (a sentence's beams: one row of parts * L columns) from the
+// per-row results of sc_topk_rows on the (G * parts, L) matrix: vals1 / idx1 (G * parts, K) -> vals / idx (G, K), idx = row-in-group * L +
+// column, descending, ties by the lower index -- exactly what sc_topk_rows returns on the (G, parts * L) view, with G * parts workgroups
+// scanning L columns each instead of G scanning parts * L.  parts * K <= 1024.
+SC_API int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, int K, int L, float* vals, long long* idx,
+                         hipStream_t stream) {
+  SC_CHECK_ARG(vals1 && idx1 && vals && idx, "sc_topk_merge: null pointer");
+  SC_CHECK_ARG(G >= 1 && G <= 65535 && parts >= 1 && K >= 1 && K <= 64 && parts * K <= 1024 && L >= K,
+               "sc_topk_merge: bad sizes G=%d parts=%d K=%d L=%d (parts * K <= 1024)", G, parts, K, L);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(G), dim3(1024), 0, stream, vals1, idx1, parts, K, L, vals, idx);
+  SC_LAUNCH_CHECK("topk_merge_kernel");
+  return SC_OK;
+}
 
 // vals / idx (R, K): the K largest elements of every row of x (R, L; row stride ld) in descending order, ties by the lower index.
 SC_API int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream) {

@@ -1890,6 +1890,23 @@ def topk_rows(x: torch.Tensor, k: int):
     return vals, idx
 
 
+_TOPK_TWO_STAGE = _os.environ.get("SC_TOPK_TWO_STAGE", "1") == "1"  # (A/B knob)
+
+
+def topk_groups(x: torch.Tensor, parts: int, k: int):
+    """`topk_rows(x.view(G, parts * L), k)` for x (G * parts, L) in two stages -- every row's own top k (G * parts workgroups over L columns
+    each), then the merge of a group's parts * k candidates (sc_topk_merge) -- with the same result, ties included."""
+    R, L = x.shape
+    G = R // parts
+    if parts == 1 or parts * k > 1024 or L < k or not _TOPK_TWO_STAGE:
+        return topk_rows(x.view(G, parts * L), k)
+    v1, i1 = topk_rows(x, k)
+    vals = torch.empty(G, k, dtype=torch.float32, device=x.device)
+    idx = torch.empty(G, k, dtype=torch.long, device=x.device)
+    lib.call("sc_topk_merge", _p(v1), _p(i1), G, int(parts), int(k), L, _p(vals), _p(idx), stream())
+    return vals, idx
+
+
 def beam_candidates(logits: torch.Tensor, beam_score: torch.Tensor, temperature: float, psi=None, psi_prev=None, ctc_weight: float = 0.0,
                     blank: int = 0, eos: int = 0, want_eos_stats: bool = False):
     """(N, V) f32 candidate scores of a beam-search step from the token head's logits (sc_beam_candidates): length-V log-softmax at

@@ -135,6 +135,29 @@ def test_beam_search_against_reference(golden, cached):
         assert torch.allclose(res["feat_token_len_ratio"].cpu(), g[f"{name}.feat_token_len_ratio"].float(), atol=1e-5), name
 
 
+@pytest.mark.parametrize("G,parts,L,K", [(32, 16, 5000, 32), (3, 4, 92, 8), (2, 16, 64, 64), (5, 1, 300, 16), (2, 40, 50, 40)])
+def test_two_stage_topk_equals_one_selection(G, parts, L, K):
+    """Fn.topk_groups (every row's own top K, then sc_topk_merge per group of `parts` rows) returns exactly what one sc_topk_rows over the
+    (G, parts * L) view returns -- values AND indices, heavy ties, -inf runs and -1e20 included (the beam search's selection must not
+    depend on which form ran)."""
+    from speechain_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(G * 11 + L)
+    x = torch.randn(G * parts, L, generator=gen)
+    x[0, : L // 2] = float("-inf")
+    x[parts - 1] = torch.randint(0, 4, (L,), generator=gen).float()  # heavy ties inside a row ...
+    if G > 1:
+        x[parts: 2 * parts] = torch.randint(0, 3, (parts, L), generator=gen).float()  # ... and across the rows of a group
+    if G > 2:
+        x[2 * parts, ::3] = -1e20
+        x[2 * parts + 1:3 * parts] = float("-inf")  # (a group whose other rows are dead beams)
+    x = x.cuda()
+    v2, i2 = Fn.topk_groups(x, parts, K)
+    v1, i1 = Fn.topk_rows(x.view(G, parts * L), K)
+    assert torch.equal(v2, v1)
+    assert torch.equal(i2, i1)
+
+
 @pytest.mark.parametrize("R,L,K", [(32, 80000, 32), (3, 92, 8), (5, 5000, 64), (2, 40, 40), (4, 1025, 2)])
 def test_topk_rows_against_torch(R, L, K):
     """sc_topk_rows: values equal torch.topk's (sorted, descending); indices point at those values; among equal values the lower index
