@@ -343,6 +343,10 @@ int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals,
 /* Second stage of the same selection over G groups of `parts` consecutive rows (beam_search.py:401-410 takes the top 2 * beam of a
  * sentence's beam * vocabulary candidates): from sc_topk_rows' per-row results (G * parts, K) to (G, K) with idx = row-in-group * L +
  * column -- identical to sc_topk_rows on the (G, parts * L) view, ties included.  parts * K <= 1024. */
+/* One launch for the step's device-to-host record: pack (B, 2 K [+ 2 beam]) float64 = [scores | indices | <eos> scores | best other scores]
+ * per sentence (infer_func/beam_search.py:401-410,455-462 read these on the host). */
+int sc_beam_pack(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, double* pack,
+                 hipStream_t stream);
 int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, int K, int L, float* vals, long long* idx, hipStream_t stream);
 
 /* Candidate scores of a beam-search step (speechain/infer_func/beam_search.py:334-345,401-410) in one pass over the token head's logits:

@@ -652,6 +652,35 @@ SC_API int sc_topk_merge(const float* vals1, const long long* idx1, int G, int p
   return SC_OK;
 }
 
+namespace {
+// row b of pack = [vals (K) | idx (K) | eos (beam) | other (beam)] as float64 (the last two blocks only when eos is given)
+__global__ __launch_bounds__(256) void beam_pack_kernel(const float* vals, const long long* idx, const float* eos, const float* other, int K, int beam,
+                                                        double* pack, int width) {
+  const int b = blockIdx.x;
+  double* row = pack + (long long)b * width;
+  for (int i = threadIdx.x; i < width; i += 256) {
+    double v;
+    if (i < K) v = (double)vals[(long long)b * K + i];
+    else if (i < 2 * K) v = (double)idx[(long long)b * K + i - K];
+    else if (i < 2 * K + beam) v = (double)eos[(long long)b * beam + i - 2 * K];
+    else v = (double)other[(long long)b * beam + i - 2 * K - beam];
+    row[i] = v;
+  }
+}
+}  // namespace
+
+// The device-to-host record of a beam-search step in one launch: pack (B, 2 K [+ 2 beam]) float64, row b = [the K candidate scores | their
+// indices | the beams' <eos> scores | the beams' best other scores] (the last two blocks with eos != null: <eos> filtering,
+// infer_func/beam_search.py:455-462).  Indices up to 2^53 are exact in float64.
+SC_API int sc_beam_pack(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, double* pack,
+                        hipStream_t stream) {
+  SC_CHECK_ARG(vals && idx && pack && B >= 1 && B <= 65535 && K >= 1 && beam >= 1 && ((eos == nullptr) == (other == nullptr)),
+               "sc_beam_pack: bad arguments");
+  hipLaunchKernelGGL(beam_pack_kernel, dim3(B), dim3(256), 0, stream, vals, idx, eos, other, K, beam, pack, 2 * K + (eos ? 2 * beam : 0));
+  SC_LAUNCH_CHECK("beam_pack_kernel");
+  return SC_OK;
+}
+
 // vals / idx (R, K): the K largest elements of every row of x (R, L; row stride ld) in descending order, ties by the lower index.
 SC_API int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream) {
   SC_CHECK_ARG(x && vals && idx, "sc_topk_rows: null pointer");

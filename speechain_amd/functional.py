@@ -1890,6 +1890,15 @@ def topk_rows(x: torch.Tensor, k: int):
     return vals, idx
 
 
+def beam_pack(vals: torch.Tensor, idx: torch.Tensor, eos: Optional[torch.Tensor], other: Optional[torch.Tensor], beam: int, pack: torch.Tensor):
+    """pack (B, 2 K [+ 2 beam]) float64 <- [vals | idx | eos | other] per sentence (sc_beam_pack)."""
+    B, K = vals.shape
+    assert pack.dtype == torch.float64 and pack.is_contiguous() and pack.shape == (B, 2 * K + (2 * beam if eos is not None else 0))
+    assert idx.dtype == torch.long and (eos is None or (eos.dtype == torch.float32 and other.dtype == torch.float32 and eos.is_contiguous()
+                                                        and other.is_contiguous() and eos.numel() == B * beam == other.numel()))
+    lib.call("sc_beam_pack", _p(vals), _p(idx), _p(eos), _p(other), B, K, int(beam), _p(pack), stream())
+
+
 _TOPK_TWO_STAGE = _os.environ.get("SC_TOPK_TWO_STAGE", "1") == "1"  # (A/B knob)
 
 

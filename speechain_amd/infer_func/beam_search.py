@@ -122,10 +122,14 @@ class _Session:
             #  32 over 80 000; same result as one selection over the sentence's beam * V candidates, ties included)
             top_scores, top_ids = Fn.topk_groups(cand.view(B * beam, V), beam, 2 * beam) if 2 * beam <= 64 else \
                 torch.topk(cand.view(B, beam * V), 2 * beam, dim=1, largest=True, sorted=True)
-            fetch = [top_scores.to(torch.float64), top_ids.to(torch.float64)]
-            if self.eos_filtering:
-                fetch += [eos_score.view(B, beam).to(torch.float64), other_max.view(B, beam).to(torch.float64)]
-            self.pack.copy_(torch.cat(fetch, dim=1))
+            if top_scores.dtype == torch.float32 and top_scores.is_contiguous() and top_ids.is_contiguous():
+                Fn.beam_pack(top_scores, top_ids, eos_score if self.eos_filtering else None, other_max if self.eos_filtering else None, beam,
+                             self.pack)  # (one launch instead of four casts, a cat and a copy)
+            else:
+                fetch = [top_scores.to(torch.float64), top_ids.to(torch.float64)]
+                if self.eos_filtering:
+                    fetch += [eos_score.view(B, beam).to(torch.float64), other_max.view(B, beam).to(torch.float64)]
+                self.pack.copy_(torch.cat(fetch, dim=1))
             self.prev_tokens.copy_(self.tokens)
 
     def step(self, pos: int) -> np.ndarray:
