@@ -79,6 +79,12 @@ class _Session:
         self.beam_idx = torch.zeros(N, dtype=torch.long, device=dev)
         self.scores = torch.zeros(N, dtype=torch.float32, device=dev)
         self.pack = torch.zeros(B, (6 if eos_filtering else 4) * beam, dtype=torch.float64, device=dev)
+        # pinned host mirrors: the step's record comes down and the next rows go up without pageable staging copies (each of those costs a
+        # host-side allocation and a blocking transfer -- four per step)
+        self.pack_host = torch.zeros(self.pack.shape, dtype=torch.float64).pin_memory()
+        self.up_scores = torch.zeros(N, dtype=torch.float32).pin_memory()
+        self.up_tokens = torch.zeros(N, dtype=torch.long).pin_memory()
+        self.up_parent = torch.zeros(N, dtype=torch.long).pin_memory()
         self.ctc = ctc_weight > 0
         if self.ctc:
             self.x = torch.empty(B, T, V, dtype=torch.float32, device=dev)
@@ -147,7 +153,19 @@ class _Session:
             g.replay()
         else:
             self._device_step(pos)
-        return self.pack.cpu().numpy()  # the step's one device-to-host copy
+        self.pack_host.copy_(self.pack, non_blocking=True)  # the step's one device-to-host copy
+        torch.cuda.current_stream(self.dev).synchronize()
+        return self.pack_host.numpy().copy()
+
+    def upload(self, scores: np.ndarray, tokens: np.ndarray, parent: np.ndarray):
+        """The next step's rows: host arrays -> pinned mirrors -> device, asynchronously (the mirrors are rewritten only after the next
+        step's synchronisation)."""
+        self.up_scores.numpy()[:] = scores
+        self.up_tokens.numpy()[:] = tokens
+        self.up_parent.numpy()[:] = parent
+        self.scores.copy_(self.up_scores, non_blocking=True)
+        self.tokens.copy_(self.up_tokens, non_blocking=True)
+        self.beam_idx.copy_(self.up_parent, non_blocking=True)
 
 
 def _session_for(fn, key, *args) -> _Session:
@@ -301,9 +319,7 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
         text = np.concatenate([text[new_parent], new_tokens[:, None]], axis=1)
         text_len = (text != padding_idx).sum(-1)
         if session is not None:
-            session.scores.copy_(torch.from_numpy(new_scores))
-            session.tokens.copy_(torch.from_numpy(new_tokens))
-            session.beam_idx.copy_(torch.from_numpy(new_parent))
+            session.upload(new_scores, new_tokens, new_parent)
             beam_scores = session.scores
             continue
         beam_scores = torch.from_numpy(new_scores).to(dev)
