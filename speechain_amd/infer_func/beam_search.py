@@ -287,31 +287,34 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
             h_ref = host[:, 5 * beam_size:6 * beam_size].astype(np.float32)
 
         # ---- selection (:423-509) ----
+        # The reference walks a sentence's 2 * beam candidates in rank order: an <eos> candidate ends a hypothesis (if it ranks inside the
+        # beam and passes the filter) and is skipped, the others are kept until `beam` rows are filled.  A row holds one <eos> token, so at most
+        # `beam` of the candidates are <eos> and the kept ones are simply the first `beam` others -- taken for all sentences at once; only
+        # the <eos> candidates in front of the last kept rank (rare) go through a Python loop.
         new_scores = np.zeros(N, dtype=np.float32)
         new_tokens = np.full(N, padding_idx, dtype=np.int64)
-        new_parent = np.zeros(N, dtype=np.int64)
-        for b in range(B):
-            if done[b]:
-                continue  # padding tokens continuing row 0, score 0 (:428-431)
-            kept = 0
-            for rank in range(2 * beam_size):
-                flat, score = int(h_ids[b, rank]), h_scores[b, rank]
-                slot, token = flat // V, flat % V
-                row = b * beam_size + slot
-                if token == sos_eos:
-                    if rank >= beam_size:
-                        continue
-                    if eos_filtering and h_eos[b, slot] <= eos_threshold * h_ref[b, slot]:
-                        continue
-                    generated_hyps[b].add(torch.from_numpy(text[row, 1:].copy()), float(score))
-                else:
-                    n = b * beam_size + kept
-                    new_scores[n], new_tokens[n], new_parent[n] = score, token, row
-                    kept += 1
-                if kept == beam_size:
-                    break
-            done[b] = generated_hyps[b].is_done(best_sum_logprobs=float(h_scores[b].max()),
-                                                curr_len=int(text_len[b * beam_size:(b + 1) * beam_size].max()) - 1)
+        new_parent = np.zeros(N, dtype=np.int64)  # (finished sentences: padding tokens continuing row 0, score 0 (:428-431))
+        slots_all, tokens_all = h_ids // V, h_ids % V
+        is_eos = tokens_all == sos_eos
+        order = np.argsort(is_eos, axis=1, kind="stable")[:, :beam_size]  # ranks of the first `beam` non-<eos> candidates, in rank order
+        r_last = order[:, -1]
+        ranks = np.arange(2 * beam_size)[None, :]
+        eos_live = is_eos & (ranks < beam_size) & (ranks < r_last[:, None])
+        active = ~np.asarray(done, dtype=bool)
+        bcol = np.arange(B)[:, None]
+        act = np.nonzero(active)[0]
+        new_scores.reshape(B, beam_size)[act] = h_scores[bcol, order][act]
+        new_tokens.reshape(B, beam_size)[act] = tokens_all[bcol, order][act]
+        new_parent.reshape(B, beam_size)[act] = (bcol * beam_size + slots_all[bcol, order])[act]
+        for b in np.nonzero(eos_live.any(axis=1) & active)[0]:
+            for rank in np.nonzero(eos_live[b])[0]:
+                slot = int(slots_all[b, rank])
+                if eos_filtering and h_eos[b, slot] <= eos_threshold * h_ref[b, slot]:
+                    continue
+                generated_hyps[b].add(torch.from_numpy(text[b * beam_size + slot, 1:].copy()), float(h_scores[b, rank]))
+        best_now, len_now = h_scores.max(axis=1), text_len.reshape(B, beam_size).max(axis=1) - 1
+        for b in act:
+            done[b] = generated_hyps[b].is_done(best_sum_logprobs=float(best_now[b]), curr_len=int(len_now[b]))
         if all(done):
             break
 
