@@ -15,6 +15,7 @@ What differs underneath:
     score mixing, top-k -- touches only buffers that live as long as the decode function and, from the second call on, is replayed from
     one hipGraph per position (``SC_DECODE_NO_GRAPH=1``: eager launches of the same code).
 """
+import contextlib
 import os
 from typing import Callable, Dict, List, Optional
 
@@ -23,6 +24,8 @@ import torch
 
 from speechain_amd import functional as Fn
 from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
+
+_CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "1") == "1"  # (A/B knob)
 
 eps = 1e-20
 minus_inf = -1e20
@@ -111,16 +114,24 @@ class _Session:
     def _device_step(self, pos: int):
         B, beam, V, w = self.B, self.beam, self.V, self.ctc_weight
         with torch.no_grad():
-            if self.ctc and pos > 0:  # forward variables and prefix scores of the candidates chosen at the last step
-                Fn.ctc_prefix_state(self.x, self.enc_lens, self.r[pos & 1 ^ 1], self.prev_tokens, pos - 1, self.beam_idx, self.tokens, beam,
-                                    self.pad, out=self.r[pos & 1])
-                self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
+            # The CTC side of a step (forward variables of the rows chosen at the last step, then the prefix scores of all their extensions:
+            # 25 + 180 us, v_exp-bound) reads the tokens and its own state only -- it runs on a second stream next to the decoder's ~70
+            # launch-latency-sized kernels and joins in front of the candidate scores (88.0 -> 85.3 ms per batch; with the decoder's chain
+            # on a high-priority stream instead: 90-94 ms).  SC_DECODE_CTC_BRANCH=0: one stream.
+            psi = None
+            side = Fn._Side(self.x, tag="ctcdec") if (self.ctc and _CTC_BRANCH) else None
+            if self.ctc:
+                with (side if side is not None else contextlib.nullcontext()):
+                    if pos > 0:
+                        Fn.ctc_prefix_state(self.x, self.enc_lens, self.r[pos & 1 ^ 1], self.prev_tokens, pos - 1, self.beam_idx, self.tokens, beam,
+                                            self.pad, out=self.r[pos & 1])
+                        self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
+                    psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
+                                               beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
             self.cache.pos = pos
             logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
-            psi = None
-            if self.ctc:
-                psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
-                                           beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
+            if side is not None:
+                side.join()
             # log-softmax of the token head, CTC mixing (:334-345) and the rows' running scores in one kernel
             cand, eos_score, other_max = Fn.beam_candidates(logits, self.scores, self.temperature, psi, self.psi_sel if (self.ctc and pos > 0) else None,
                                                             w, self.pad, self.sos_eos, want_eos_stats=self.eos_filtering)
