@@ -269,9 +269,14 @@ class _WeightCache:
             cur = self._desc.get(code)
             if cur is None or cur[0] != sig:
                 recs, tile0 = [], 0
+                bykey = dict(ents)
                 for k, v in ents:
                     buf, params = v[1], [r() for r in v[2]]
                     transposed = len(k) == 3 and k[2] in ("T", "D")  # ("D": the transposed copy with its (tap, channel) rows re-ordered)
+                    # a plain copy and the transposed copy of the same parameters share their records: the source is read once
+                    if len(k) == 3 and k[2] == "T" and (k[0], k[1]) in bykey:
+                        continue
+                    partner = bykey.get((k[0], k[1], "T")) if (len(k) == 2 and k[1] != "vec") else None
                     r = 0
                     for p in params:
                         assert p.is_contiguous() and p.dtype == torch.float32
@@ -284,6 +289,10 @@ class _WeightCache:
                             if transposed:
                                 ldt = rows if k[2] == "D" else buf.size(1)  # ("D" is stored as (C, k N): its (C k, N) rows are N long)
                                 rec = (p.data_ptr(), 0, buf.data_ptr() + esz * r, rows, cols, 0, ldt, tile0, (cols + 63) // 64)
+                            elif partner is not None:
+                                bt = partner[1]
+                                rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, bt.data_ptr() + esz * r, rows, cols, cols, bt.size(1), tile0,
+                                       (cols + 63) // 64)
                             else:
                                 rec = (p.data_ptr(), buf.data_ptr() + esz * r * cols, 0, rows, cols, cols, 0, tile0, (cols + 63) // 64)
                             r += rows
