@@ -243,3 +243,25 @@ def test_conv_feed_forward_without_im2col_equals_the_im2col_path(monkeypatch, T,
     finally:
         Fn.GradSinks.clear()
         Fn.set_compute_dtype(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,r", [(3, 50, 64, 1), (2, 7, 8, 2), (4, 128, 384, 1)])
+def test_pad_rows_through_the_c_abi(B, T, C, r):
+    """sc_pad_rows / sc_zero_pad_rows against a torch construction of the image: r zero rows on either side of every utterance, zero rows
+    behind the last one; the second entry point writes exactly those zero rows and leaves the data rows alone."""
+    from speechain_amd._lib import lib, stream
+
+    gen = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, T, C, generator=gen).cuda().bfloat16()
+    rows = (B * (T + 2 * r) + 31) // 32 * 32 + 32
+    want = torch.zeros(rows, C, dtype=torch.bfloat16, device="cuda")
+    want[: B * (T + 2 * r)].view(B, T + 2 * r, C)[:, r: r + T] = x
+    out = torch.full((rows, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lib.call("sc_pad_rows", Fn._p(x), B, T, C, r, Fn._p(out), rows, stream())
+    assert torch.equal(out, want)
+    out2 = torch.full((rows, C), 7.0, dtype=torch.bfloat16, device="cuda")
+    lib.call("sc_zero_pad_rows", B, T, C, r, Fn._p(out2), rows, stream())
+    keep = torch.zeros(rows, dtype=torch.bool, device="cuda")
+    keep[: B * (T + 2 * r)].view(B, T + 2 * r)[:, r: r + T] = True
+    assert torch.equal(out2[keep], torch.full_like(out2[keep], 7.0)) and torch.equal(out2[~keep], torch.zeros_like(out2[~keep]))
