@@ -677,7 +677,8 @@ class ASRDecodeWorkload:
         from speechain_amd._lib import lib
 
         if instrument:
-            names = ("sc_ctc_prefix_scores", "sc_ctc_prefix_state", "sc_attention_decode", "sc_attention_fwd", "sc_gemm", "sc_layernorm_fwd")
+            names = ("sc_ctc_prefix_scores", "sc_ctc_prefix_scores_fast", "sc_ctc_prefix_state", "sc_attention_decode", "sc_attention_fwd", "sc_gemm",
+                     "sc_layernorm_fwd")
             lib.timing = {k: [] for k in names}
         from speechain_amd.infer_func import beam_search as BS
 
@@ -693,15 +694,18 @@ class ASRDecodeWorkload:
     def roofline(self):
         """The CTC prefix-score kernel: per launch it reads the (B, T, V) f32 log-probabilities once per beam row group (L2 serves the
         15 other beams of a sentence) and writes psi (N, V); exp-bound rather than byte-bound at these sizes -- both figures are given."""
-        n, ms = self.kernel_ms["sc_ctc_prefix_scores"]
+        fast = self.kernel_ms.get("sc_ctc_prefix_scores_fast", (0, 0.0))[0] > 0  # (the factorised form: the default)
+        n, ms = self.kernel_ms["sc_ctc_prefix_scores_fast" if fast else "sc_ctc_prefix_scores"]
         per = ms / max(n, 1)
         T, V, N = 249, ASR_MODEL["vocab_size"], BATCH * DECODE_CONF["beam_size"]
         alg = BATCH * T * V * 4 + N * V * 4 + T * 2 * N * 4
         achieved = alg / (per * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "ctc_psi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
-                "note": f"{N * V * (T - 1) / (per * 1e-3) / 1e12:.2f} T exp/s: one v_exp per (row, token, frame); launches per batch "
-                        + ", ".join(f"{k} {c} x {t / max(c, 1) * 1e3:.1f} us" for k, (c, t) in self.kernel_ms.items())}
+        rate = N * V * (T - 1) / (per * 1e-3) / 1e12
+        return {"bound": "hbm", "kernel": "ctc_psi_fast_kernel" if fast else "ctc_psi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
+                "note": (f"{rate:.2f} T multiply-adds/s: one per (row, token, frame), the exponential's second factor made once per batch; "
+                         if fast else f"{rate:.2f} T exp/s: one v_exp per (row, token, frame); ") + "launches per batch "
+                        + ", ".join(f"{k} {c} x {t / max(c, 1) * 1e3:.1f} us" for k, (c, t) in self.kernel_ms.items() if c)}
 
 
 def cpu_baseline_decode(seconds: float):

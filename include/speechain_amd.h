@@ -334,6 +334,11 @@ int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache
  *     extended by tokens[n] -- recomputed for those N pairs (the reference gathers them out of a (T, 2, N, V) tensor, :162-196). */
 int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev, const long long* last, float* psi,
                          int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream);
+/* The same scores with the exponential factorised (exp(phi + x) = exp(phi - a) * exp(x - bmax)): E (B, T, V) = exp(x - bmax) and bmax (B, V) =
+ * max over the frames of x are made once per batch by the caller; a step is then one multiply-add per (row, token, frame) instead of
+ * one v_exp.  Sums that underflow are redone exactly per (row, token): the result is sc_ctc_prefix_scores' up to f32 rounding of the sum. */
+int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float* bmax, const int* enc_lens, const int* eos_frame, const float* r_prev,
+                              const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream);
 int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
                         const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream);
 

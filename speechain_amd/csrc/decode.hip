@@ -319,6 +319,92 @@ __global__ __launch_bounds__(256) void ctc_psi_kernel(const float* x, const int*
   }
 }
 
+// The same scores with the exponential factorised: exp(phi[t-1] + x[t][c]) = exp(phi[t-1] - a) * exp(x[t][c] - bmax[c]), the second factor
+// E (B, T, V) computed ONCE per batch (sc_ctc_prefix_scores_fast), the first (RPB x 2 x T values) once per workgroup -- the sweep over the frames is
+// one multiply-add per (row, candidate, frame) instead of add / sub / exp / add after a separate maximum sweep.
+//   psi = a + bmax[c] + log( exp(first - a - bmax[c]) + sum_t P[t-1] E[t][c] ),   a = max of the phi row over the frames the sum reads.
+// A sum that underflows (its largest term more than ~87 below a + bmax[c]: hopeless candidates, or rows that are impossible altogether)
+// is redone for that (row, candidate) by the exact two-sweep form, so every score is the exact kernel's up to f32 rounding of the sum.
+template <int RPB>
+__global__ __launch_bounds__(256) void ctc_psi_fast_kernel(const float* x, const float* E, const float* bmax, const int* enc_lens,
+                                                           const int* eos_frame, const float* r_prev, const long long* last, float* psi, int N,
+                                                           int T, int V, int beam, int plen, int blank, int eos) {
+  extern __shared__ float s_all[];  // [RPB][2][T] phi (r_sum, r_blank), then [RPB][2][T] P = exp(phi - a), then a[RPB][2]
+  float* s_phi = s_all;
+  float* s_P = s_all + RPB * 2 * T;
+  float* s_a = s_P + RPB * 2 * T;
+  const int n0 = blockIdx.y * RPB, b = n0 / beam;
+  const int start = plen > 1 ? plen : 1;
+  for (int i = threadIdx.x; i < RPB * T; i += 256) {
+    const int r = i / T, t = i - r * T;
+    const float r0 = r_prev[((long long)t * 2 + 0) * N + n0 + r], r1 = r_prev[((long long)t * 2 + 1) * N + n0 + r];
+    s_phi[(r * 2 + 0) * T + t] = logaddexpf(r0, r1);
+    s_phi[(r * 2 + 1) * T + t] = r1;
+  }
+  __syncthreads();
+  {  // a = max over the frames t - 1 = start - 1 .. T - 2 of each of the 2 RPB rows: one wave per row, rows dealt round-robin
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int row = w; row < 2 * RPB; row += 4) {
+      float mx = -INFINITY;
+      for (int t = start - 1 + lane; t < T - 1; t += 64) mx = fmaxf(mx, s_phi[row * T + t]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if (lane == 0) s_a[row] = (mx == -INFINITY) ? 0.f : mx;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * RPB * T; i += 256) s_P[i] = __expf(s_phi[i] - s_a[i / T]);
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= V) return;
+  const int len = enc_lens[b];
+  const float* xc = x + (long long)b * T * V + c;
+  const float* Ec = E + (long long)b * T * V + c;
+  const float bc = bmax[(long long)b * V + c];
+  const float pad_x = (c == blank) ? 0.f : CTC_IMPOSSIBLE;
+  const float e_pad = __expf(pad_x - bc);
+  const float first = (plen == 0) ? ((0 < len) ? xc[0] : pad_x) : CTC_IMPOSSIBLE;
+  int var[RPB];
+  float S[RPB];
+  unsigned exact = 0;  // rows of this candidate that take the exact form
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    const long long lastc = plen > 0 ? last[n0 + r] : 0;
+    var[r] = r * 2 + (c == lastc ? 1 : 0);
+    const float f0 = first - s_a[var[r]] - bc;  // (the empty prefix's first term is not scaled by phi: it may tower over a + bmax[c])
+    if (f0 > 80.f) exact |= 1u << r;
+    S[r] = f0 > 80.f ? 0.f : __expf(f0);
+  }
+  for (int t0 = start; t0 < T; t0 += 8) {
+    float el[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) el[u] = (t0 + u < len) ? Ec[(long long)(t0 + u) * V] : e_pad;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + u < T) {
+#pragma unroll
+        for (int r = 0; r < RPB; ++r) S[r] = fmaf(s_P[var[r] * T + t0 + u - 1], el[u], S[r]);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    float out;
+    if (S[r] > 1e-30f && !((exact >> r) & 1u)) {
+      out = s_a[var[r]] + bc + __logf(S[r]);
+    } else {  // underflow (or an impossible row): the exact form for this (row, candidate)
+      const float* phi = s_phi + var[r] * T;
+      float m = first;
+      for (int t = start; t < T; ++t) m = fmaxf(m, phi[t - 1] + ((t < len) ? xc[(long long)t * V] : pad_x));
+      float sum = __expf(first - m);
+      for (int t = start; t < T; ++t) sum += __expf(phi[t - 1] + ((t < len) ? xc[(long long)t * V] : pad_x) - m);
+      out = m + __logf(sum);
+    }
+    if (c == eos) out = s_phi[(r * 2 + 0) * T + eos_frame[n0 + r]];
+    if (c == blank) out = CTC_IMPOSSIBLE;
+    psi[(long long)(n0 + r) * V + c] = out;
+  }
+}
+
 // An affine map r -> logaddexp(a + r, b) in the log domain (R -> A R + B in the probability domain), and "g after f".
 struct LogAffine {
   float a, b;
@@ -423,6 +509,32 @@ SC_API int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* 
   else SC_LAUNCH_PSI(1);
 #undef SC_LAUNCH_PSI
   SC_LAUNCH_CHECK("ctc_psi_kernel");
+  return SC_OK;
+}
+
+// The same scores from the factorised exponential: E (B, T, V) = exp(x - bmax) and bmax (B, V) = max over the frames of x, made once per
+// batch by the caller (two torch launches).  Results equal sc_ctc_prefix_scores' up to the f32 rounding of a 250-term sum.
+SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float* bmax, const int* enc_lens, const int* eos_frame,
+                                     const float* r_prev, const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank,
+                                     int eos, hipStream_t stream) {
+  SC_CHECK_ARG(x && E && bmax && enc_lens && eos_frame && r_prev && psi && (last || plen == 0), "sc_ctc_prefix_scores_fast: null pointer");
+  SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 2 && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
+                   (long long)B * beam <= 65535, "sc_ctc_prefix_scores_fast: bad sizes B=%d beam=%d T=%d V=%d plen=%d", B, beam, T, V, plen);
+  const int N = B * beam;
+  int rpb = beam % 8 == 0 ? 8 : beam % 4 == 0 ? 4 : beam % 2 == 0 ? 2 : 1;
+  while (rpb > 1 && (size_t)rpb * (4 * T + 2) * sizeof(float) > 64 * 1024) rpb >>= 1;
+  const size_t smem = (size_t)rpb * (4 * T + 2) * sizeof(float);
+  SC_CHECK_ARG(smem <= 64 * 1024, "sc_ctc_prefix_scores_fast: T too large for the LDS rows (%d frames x %d rows)", T, rpb);
+  const dim3 grid(sc_cdiv(V, 256), N / rpb);
+#define SC_LAUNCH_PSI(R)                                                                                                              \
+  hipLaunchKernelGGL(ctc_psi_fast_kernel<R>, grid, dim3(256), smem, stream, x, E, bmax, enc_lens, eos_frame, r_prev, last, psi, N, T, V, beam, \
+                     plen, blank, eos)
+  if (rpb == 8) SC_LAUNCH_PSI(8);
+  else if (rpb == 4) SC_LAUNCH_PSI(4);
+  else if (rpb == 2) SC_LAUNCH_PSI(2);
+  else SC_LAUNCH_PSI(1);
+#undef SC_LAUNCH_PSI
+  SC_LAUNCH_CHECK("ctc_psi_fast_kernel");
   return SC_OK;
 }
 

@@ -1864,13 +1864,26 @@ def ctc_prefix_init(x: torch.Tensor, enc_lens: torch.Tensor, beam: int, blank: i
     return r
 
 
-def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None) -> torch.Tensor:
+def ctc_prefix_factors(x: torch.Tensor):
+    """(E, bmax) for `ctc_prefix_scores(..., factors=...)`: bmax (B, V) = max over the frames of the log-probabilities x (B, T, V),
+    E = exp(x - bmax) -- made once per batch, they turn a step's scores into multiply-adds (sc_ctc_prefix_scores_fast)."""
+    bmax = x.max(dim=1).values.contiguous()
+    return torch.exp(x - bmax[:, None, :]).contiguous(), bmax
+
+
+def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None, factors=None) -> torch.Tensor:
     """psi (N, V) of every candidate token of every hypothesis row (sc_ctc_prefix_scores); r_prev None = the empty prefix."""
     require_gpu(x, "ctc_prefix_scores")
     B, T, V = x.shape
     if r_prev is None:
         r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
     psi = out if out is not None else torch.empty(B * beam, V, dtype=torch.float32, device=x.device)
+    if factors is not None and T >= 2:
+        E, bmax = factors
+        assert E.shape == x.shape and E.is_contiguous() and bmax.shape == (B, V) and bmax.is_contiguous()
+        lib.call("sc_ctc_prefix_scores_fast", _p(x), _p(E), _p(bmax), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B,
+                 beam, T, V, int(plen), int(blank), int(eos), stream())
+        return psi
     lib.call("sc_ctc_prefix_scores", _p(x), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B, beam, T, V, int(plen),
              int(blank), int(eos), stream())
     return psi

@@ -26,6 +26,7 @@ from speechain_amd import functional as Fn
 from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
 
 _CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "1") == "1"  # (A/B knob)
+_CTC_PSI_FAST = os.environ.get("SC_CTC_PSI_FAST", "1") == "1"  # (A/B knob: 0 = one v_exp per (row, token, frame))
 
 eps = 1e-20
 minus_inf = -1e20
@@ -96,6 +97,9 @@ class _Session:
             self.r = [torch.empty(T, 2, N, dtype=torch.float32, device=dev) for _ in range(2)]
             self.psi = [torch.empty(N, V, dtype=torch.float32, device=dev) for _ in range(2)]
             self.psi_sel = torch.empty(N, dtype=torch.float32, device=dev)
+            # factors of the prefix scores' exponential, made once per batch in begin() (Fn.ctc_prefix_factors, into these static buffers)
+            self.E = torch.empty(B, T, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
+            self.bmax = torch.empty(B, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
         self.cache, self.graphs, self.pool, self.calls = None, {}, None, 0
         self.use_graphs = os.environ.get("SC_DECODE_NO_GRAPH", "0") != "1"
 
@@ -110,6 +114,10 @@ class _Session:
             self.enc_lens.copy_(scorer.enc_lens)
             self.eos_frame.copy_(scorer.eos_frame)
             self.r[0].copy_(Fn.ctc_prefix_init(self.x, self.enc_lens, self.beam, self.pad))
+            if self.E is not None:
+                self.bmax.copy_(self.x.max(dim=1).values)
+                torch.sub(self.x, self.bmax[:, None, :], out=self.E)
+                self.E.exp_()
 
     def _device_step(self, pos: int):
         B, beam, V, w = self.B, self.beam, self.V, self.ctc_weight
@@ -127,7 +135,8 @@ class _Session:
                                             self.pad, out=self.r[pos & 1])
                         self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
                     psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
-                                               beam, self.pad, self.sos_eos, out=self.psi[pos & 1])
+                                               beam, self.pad, self.sos_eos, out=self.psi[pos & 1],
+                                               factors=(self.E, self.bmax) if self.E is not None else None)
             self.cache.pos = pos
             logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
             if side is not None:

@@ -285,3 +285,28 @@ def test_cached_and_prefix_beam_search_agree_at_recipe_width():
         got = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=dec, ctc_decode_fn=ctc, **kw)
         assert torch.equal(got["hypo_text"], want["hypo_text"]) and torch.equal(got["hypo_text_len"], want["hypo_text_len"])
         assert torch.allclose(got["hypo_text_confid"], want["hypo_text_confid"], atol=1e-3)
+
+
+@pytest.mark.parametrize("plen", [0, 1, 3, 9])
+def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen):
+    """sc_ctc_prefix_scores_fast (exp(phi + x) = exp(phi - a) exp(x - bmax), the second factor made once per batch) against the exact
+    two-sweep kernel on peaky log-probabilities with ragged lengths, impossible rows and forward variables far apart: every score within
+    2e-4 absolute + 2e-6 relative, <eos> / blank columns identical."""
+    from speechain_amd import functional as Fn
+
+    B, beam, T, V, blank, eos = 3, 8, 61, 300, 0, 299
+    gen = torch.Generator().manual_seed(40 + plen)
+    logits = torch.randn(B, T, V, generator=gen) * 6.0  # peaky: log-probabilities from about -0.01 down to -50
+    x = torch.log_softmax(logits, dim=-1).cuda()
+    enc_lens = torch.tensor([T, 47, 30], dtype=torch.int32).cuda()
+    N = B * beam
+    r = torch.randn(T, 2, N, generator=gen) * 30.0 - 40.0  # forward variables spread over ~100 nats
+    r[: max(plen - 1, 0)] = -1e20  # frames before the prefix could have been emitted
+    r[:, :, 5] = -1e20  # an impossible row
+    r = r.cuda()
+    eos_frame = (enc_lens.repeat_interleave(beam) - 1).to(torch.int32)
+    last = torch.randint(1, V - 1, (N,), generator=gen).cuda()
+    want = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r, last if plen > 0 else None, plen, beam, blank, eos)
+    got = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r, last if plen > 0 else None, plen, beam, blank, eos, factors=Fn.ctc_prefix_factors(x))
+    assert torch.equal(got[:, blank], want[:, blank]) and torch.equal(got[:, eos], want[:, eos])
+    assert torch.allclose(got, want, atol=2e-4, rtol=2e-6), float((got - want).abs().max())
