@@ -521,7 +521,8 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 2 && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
                    (long long)B * beam <= 65535, "sc_ctc_prefix_scores_fast: bad sizes B=%d beam=%d T=%d V=%d plen=%d", B, beam, T, V, plen);
   const int N = B * beam;
-  int rpb = beam % 8 == 0 ? 8 : beam % 4 == 0 ? 4 : beam % 2 == 0 ? 2 : 1;
+  // (16 rows per workgroup when the beam allows: the (B, T, V) factor is then read once per sentence and step)
+  int rpb = beam % 16 == 0 ? 16 : beam % 8 == 0 ? 8 : beam % 4 == 0 ? 4 : beam % 2 == 0 ? 2 : 1;
   while (rpb > 1 && (size_t)rpb * (4 * T + 2) * sizeof(float) > 64 * 1024) rpb >>= 1;
   const size_t smem = (size_t)rpb * (4 * T + 2) * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_ctc_prefix_scores_fast: T too large for the LDS rows (%d frames x %d rows)", T, rpb);
@@ -529,7 +530,8 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
 #define SC_LAUNCH_PSI(R)                                                                                                              \
   hipLaunchKernelGGL(ctc_psi_fast_kernel<R>, grid, dim3(256), smem, stream, x, E, bmax, enc_lens, eos_frame, r_prev, last, psi, N, T, V, beam, \
                      plen, blank, eos)
-  if (rpb == 8) SC_LAUNCH_PSI(8);
+  if (rpb == 16) SC_LAUNCH_PSI(16);
+  else if (rpb == 8) SC_LAUNCH_PSI(8);
   else if (rpb == 4) SC_LAUNCH_PSI(4);
   else if (rpb == 2) SC_LAUNCH_PSI(2);
   else SC_LAUNCH_PSI(1);
