@@ -1,12 +1,16 @@
 """bench.py -- throughput of the MI355X hot path on synthetic 10 s @ 16 kHz x 32 batches.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload asr_train_step|frontend|tts_train_step|asr_decode]
 
-One process per GPU (N > 1: launched by torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE from the env).  A step is
-one pass of the hot path over one per-GPU batch of 32 synthetic utterances; inputs are resident in HBM before the
-timed region.  The path shards by utterance with no data-path collective (weak scaling).  Rank 0 prints ONE JSON
-line (see the repo prompt's contract) with two extra objects:
-  roofline     -- algorithmic bytes of the dominant kernel / its HIP-event-measured launch time vs the 8 TB/s HBM peak
+One process per GPU.  N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the environment), or -- with no
+launcher around it -- this script starts its N ranks itself as child processes (`self_launch`).  A step is one pass of the hot path over
+one per-GPU batch of 32 synthetic utterances; inputs are resident in HBM before the timed region; every timed step of the train-step
+workloads replays the same hipGraphs.  The path shards by utterance (weak scaling): the only exchanges are the gradient all-reduce, the
+feature-normalisation statistics and the BatchNorm statistics (SyncBatchNorm, as the reference's DDP set-up).  Rank 0 prints ONE JSON line
+(see the repo prompt's contract) with two extra objects:
+  roofline     -- the dominant kernel against the bound that applies to it: for the train steps the GEMM kernel with the largest summed
+                  time vs the 2.5 PFLOP/s dense bf16 MFMA peak (flops / HIP-event time of ONE extra eager, instrumented step that runs right
+                  AFTER the timed region); for the frontend its algorithmic bytes / HIP-event launch time vs the 8 TB/s HBM peak
   cpu_baseline -- the CPU oracle (a torch-CPU port of the reference op sequence) timed on this host's cores on a
                   bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -32,8 +36,7 @@ BATCH, SAMPLES = 32, 160000
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (100 timed steps by default, ~1.3 s: ONE of them runs eagerly with HIP events around every GEMM launch -- the roofline must be
-    #  measured inside the timed region -- and takes ~26 ms instead of ~12.7; over 20 steps that alone adds 0.65 ms to the average)
+    # (100 timed steps by default, under a second of replayed graphs; the eager, event-instrumented step of the roofline runs AFTER them)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="asr_train_step", choices=["asr_train_step", "frontend", "tts_train_step", "asr_decode"],
@@ -43,6 +46,9 @@ def parse():
     ap.add_argument("--prenet-dims", default="64,64",
                     help="conv channels of the Conv2d prenet in front of the encoder (SURVEY row f2; HIP path, FLOPs outside the named-path count). "
                          "64,64 = the transformer-wide recipes (and the module default); 512,512 = the transformer-large recipes (conv_dims = d_model)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the N ranks up (RCCL process group, or gloo where there is no GPU), all-reduce one number, print "
+                         '{"launch_check": "ok", ...} and exit: what tests/test_bench_launch.py runs on CPU')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -149,6 +155,10 @@ class ASRTrainStepWorkload:
         self.norm = FeatureNormalization(input_size=80, distributed=distributed).to(device).train()
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device).train()
         self.prenet = Conv2dPrenet(input_size=80, **prenet_conf(self.prenet_dims)).to(device).train()
+        if distributed and os.environ.get("BENCH_SYNCBN", "1") == "1":
+            # speechain/runner.py:1856-1858 (`enable_syncbatchnorm`, default True): every BatchNorm of a DDP model normalises with the
+            # statistics of the batches of ALL ranks -- the HIP prenet all-reduces its C-sized sums between its reduce and finish kernels
+            self.prenet = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.prenet)
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
         for m in (self.prenet, self.model):
             for p in m.parameters():
@@ -169,6 +179,7 @@ class ASRTrainStepWorkload:
         self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, process_group=grad_pg, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
         self.lr = torch.tensor([2e-3], device=device)
+        self.noam_warmup = 25000  # (tests/test_bench_path_gpu.py shortens it so that a handful of steps moves the weights)
         # clip at 5.0 + Adam(0.9, 0.98, 1e-9) over the flat buckets in two launches (csrc/optim.hip); BENCH_TORCH_ADAM=1: stock torch ops
         self.fused_opt = os.environ.get("BENCH_TORCH_ADAM", "0") != "1"
         if self.fused_opt:
@@ -353,7 +364,7 @@ class ASRTrainStepWorkload:
 
         self.nstep += 1
         # Noam schedule, warmup 25000 (optim_sche/noam.py:42-59): a scalar fill outside the graphs
-        self.lr.fill_(2e-3 * min(self.nstep ** -0.5, self.nstep * 25000 ** -1.5) * 25000 ** 0.5)
+        self.lr.fill_(2e-3 * min(self.nstep ** -0.5, self.nstep * self.noam_warmup ** -1.5) * self.noam_warmup ** 0.5)
         self._load_batch()
         graph = self.use_graph and not instrument and self.nstep > 3
         if graph and self.g_body is None:
@@ -509,6 +520,8 @@ class TTSTrainStepWorkload:
         Fn.set_attention_probs(False)
         torch.manual_seed(0)
         self.model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf(*TTS_DROPOUT)).to(device).train()
+        if distributed and os.environ.get("BENCH_SYNCBN", "1") == "1":  # (the postnet's BatchNorm1d blocks: runner.py:1856-1858)
+            self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
         for p in self.model.parameters():
             if p.dim() > 1:
                 torch.nn.init.xavier_normal_(p)
@@ -516,6 +529,7 @@ class TTSTrainStepWorkload:
         self.reducer = GradBucketReducer(self.params, bucket_mb=32.0, adjacent=attention_fusion_groups(self.model))
         self.reducer.broadcast_parameters()
         self.lr = torch.tensor([1e-3], device=device)
+        self.noam_warmup = 6000
         self.opt = FusedAdam(self.reducer, self.lr, betas=(0.9, 0.98), eps=1e-9, max_grad_norm=1.0)
         torch.manual_seed(1234 + seed)
         self.batch = synth_tts(seed, device)
@@ -542,7 +556,7 @@ class TTSTrainStepWorkload:
         from speechain_amd._lib import lib
 
         self.nstep += 1
-        self.lr.fill_(384 ** -0.5 * min(self.nstep ** -0.5, self.nstep * 6000 ** -1.5))
+        self.lr.fill_(384 ** -0.5 * min(self.nstep ** -0.5, self.nstep * self.noam_warmup ** -1.5))
         # head, eager: frontend (mel + energy), the three normalisations (their running statistics are re-created on every call), frame counts per
         # token, per-token pitch / energy targets -> the static inputs of the captured body
         # Like the ASR workload's head, it depends on the data only: the head of batch i+1 runs on a second stream while the graphs of batch i
@@ -853,8 +867,74 @@ def cpu_baseline(seconds: float):
                 sample=f"{n} batches of 32x160000 samples (frontend+specaug, torch-CPU oracle, fp32, {cores} threads)")
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it (no RANK / WORLD_SIZE in the environment): start the N ranks here, one child
+    process per GPU, as the reference's runner does with mp.spawn (speechain/runner.py:2014).  The parent never touches the GPU (children
+    are fresh interpreters started before any HIP call -- never an exec of a process that initialised the device); it relays rank 0's one
+    JSON line and returns non-zero if any rank failed (the other ranks are then ended, by the PIDs started here)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)  # (drain rank 0's pipe while polling all ranks)
+    reader.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench: rank {r} exited with code {code}; ending the other ranks", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    if rc == 0:
+        sys.stdout.write(out0[0] if out0 else "")
+        sys.stdout.flush()
+    return rc
+
+
+def launch_check(args, rank, local_rank, world):
+    """--launch-check: process group up, one all-reduce, one line."""
+    import torch.distributed as dist
+
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
+    if world > 1:
+        dist.init_process_group(backend="nccl" if gpu else "gloo", **({"device_id": dev} if gpu else {}))
+    t = torch.tensor([float(rank + 1)], device=dev)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    ok = float(t.item()) == world * (world + 1) / 2
+    return {"launch_check": "ok" if ok else "sum mismatch", "world": world, "backend": ("nccl" if gpu else "gloo") if world > 1 else None,
+            "sum": float(t.item())}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries print there too (RCCL writes a version banner to
     # stdout when the process group comes up), so file descriptor 1 points at stderr until that line is written.
     sys.stdout.flush()
@@ -863,6 +943,17 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run, or with no launcher at all)"
+    if args.launch_check:
+        res = launch_check(args, rank, local_rank, world)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(res), flush=True)
+            os.dup2(2, 1)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        sys.exit(0 if res["launch_check"] == "ok" else 1)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -877,7 +968,6 @@ def main():
         if force_dist:
             os.environ["SC_DDP_FORCE_COLLECTIVES"] = "1"
         dist.init_process_group(backend="nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     torch.manual_seed(1234 + rank)
     prenet_dims = tuple(int(c) for c in args.prenet_dims.split(","))

@@ -131,9 +131,9 @@ int sc_featnorm_apply(const float* feat, float* out, long long stride_b, long lo
 long long sc_conv1_moments_workspace(int B, int Ti, int Fi, int To, int Fo, int KH, int KW, int SH, int SW, int PH, int PW);
 int sc_conv1_moments(const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
                      int SH, int SW, int PH, int PW, double* moments, void* workspace, long long ws_bytes, hipStream_t stream);
-int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const float* gamma, const float* beta,
-                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
-                       float* rstd, hipStream_t stream);
+int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const double* count_dev,
+                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* scale, float* shift, float* mean, float* rstd, hipStream_t stream);
 int sc_conv1_apply(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH,
                    int KW, int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act,
                    float slope, void* y, hipStream_t stream);
@@ -142,6 +142,35 @@ int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride
                  int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act, float slope,
                  const void* dy, const double* moments, const float* gamma, const float* mean, const float* rstd, int batch_stats,
                  float* dw, float* dgamma, float* dbeta, void* workspace, long long ws_bytes, hipStream_t stream);
+
+/* Synchronised batch statistics (torch.nn.SyncBatchNorm, which the reference's DDP set-up turns every BatchNorm into:
+ * speechain/runner.py:303-310 `enable_syncbatchnorm` default True, :1856-1858 convert_sync_batchnorm before the DDP wrap).  Mean and
+ * variance are those of the batches of ALL ranks: the per-rank sums (the float64 moment / sum vectors below) are all-reduced by the
+ * caller between the two phases of each entry point above, which exist separately for that purpose:
+ *   forward, first block:  sc_conv1_moments -> [all-reduce moments, count] -> sc_conv1_bn_coeffs(count_dev = the summed count)
+ *   backward, first block: sc_conv1_bwd_reduce (gsum[C][KK + 1] = sum g.patch_k, sum g) -> [all-reduce] -> sc_conv1_bwd_finish
+ *   forward, other blocks: sc_bn_sums(dy = null) (sums[2][C] = sum z, sum z^2) -> [all-reduce] -> sc_bn_stats_finish
+ *   backward:              sc_bn_sums(dy) (sum g, sum g z) -> [all-reduce] -> sc_bn_bwd_finish (coef[3][C]) -> sc_bn_bwd_apply
+ * The *_finish kernels take the rank's own sums for what it contributes to dgamma / dbeta / dw (the gradient all-reduce averages the ranks
+ * afterwards, as DDP does for SyncBatchNorm) and the all-rank sums (`*_all`, `count_dev`: one float64 on the device) for the terms that
+ * come from differentiating the statistics; null `*_all` / `count_dev` = one rank (`count` is used).  `moments` of sc_conv1_bwd_finish are
+ * THIS rank's.  sc_conv1_bwd / sc_bn_stats / sc_bn_act_bwd are the one-rank compositions.  Workspaces: sc_conv1_bwd_reduce needs
+ * sc_conv1_bwd_workspace(..) - C*(KK+1)*8 bytes, sc_bn_sums needs sc_bn_workspace(M, C) - 16*C bytes. */
+int sc_conv1_bwd_reduce(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH,
+                        int KW, int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act,
+                        float slope, const void* dy, double* gsum, void* workspace, long long ws_bytes, hipStream_t stream);
+int sc_conv1_bwd_finish(const double* gsum, const double* gsum_all, const double* moments, const float* w, int C, int KK, long long count,
+                        const double* count_dev, const float* gamma, const float* mean, const float* rstd, int batch_stats, float* dw,
+                        float* dgamma, float* dbeta, hipStream_t stream);
+int sc_bn_sums(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, int act, float slope,
+               double* sums, void* workspace, long long ws_bytes, hipStream_t stream);
+int sc_bn_stats_finish(const double* sums, int C, long long count, const double* count_dev, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                       hipStream_t stream);
+int sc_bn_bwd_finish(const double* sums, const double* sums_all, int C, long long count, const double* count_dev, const float* scale,
+                     const float* mean, const float* rstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream);
+int sc_bn_bwd_apply(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, const float* coef,
+                    int act, float slope, void* dz, hipStream_t stream);
 
 /* Blocks with C input channels (nn.Conv2d(C, C_out) at conv2d.py:171-180 as im2col + sc_gemm; its autograd as sc_gemm_splitk / sc_gemm +
  * sc_col2im):  col[(b, to, fo)][(kh, kw, c)] = a[b][to*SH - PH + kh][fo*SW - PW + kw][c] (0 outside the image);

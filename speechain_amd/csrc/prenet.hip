@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* x, long
 
 // BatchNorm2d coefficients of channel c from the moments (training): scale = gamma * rstd, shift = beta - mean * scale; the
 // running statistics move by `momentum` with the UNBIASED variance (torch.nn.BatchNorm2d).
-__global__ void conv1_bn_coeffs_kernel(const double* moments, const float* w, int C, int KK, double count, const float* gamma,
-                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                       float* scale, float* shift, float* mean, float* rstd) {
+__global__ void conv1_bn_coeffs_kernel(const double* moments, const float* w, int C, int KK, double count, const double* count_dev,
+                                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                       float* running_var, float* scale, float* shift, float* mean, float* rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;  // (synchronised statistics: the positions of ALL ranks, summed on the device)
   const double* S = moments;
   const double* P = moments + KK * KK;
   double m = 0.0, e2 = 0.0;
@@ -355,22 +356,32 @@ __global__ __launch_bounds__(256) void conv1_bwd_reduce_kernel(const float* x, l
 
 // dW[c][k], dgamma, dbeta of the first block from the reduced G, sum g and the forward moments (see the file header).
 // Gsum: [C][KK + 1] float64 (sum_partials_kernel over the groups).
-__global__ void conv1_bwd_finish_kernel(const double* Gsum, const double* moments, const float* w, int C, int KK, double count,
-                                        const float* gamma, const float* mean, const float* rstd, int batch_stats, float* dw,
-                                        float* dgamma, float* dbeta) {
+// Synchronised statistics (torch.nn.SyncBatchNorm: mean / variance over the batches of ALL ranks): `Gglob` holds the sums of all ranks and
+// `count_dev` their position count; mean / rstd are the global ones.  What this rank contributes to the parameter gradients uses ITS sums
+// (G, S, P: the gradient all-reduce averages the ranks afterwards), the terms that come from differentiating the statistics use the global
+// ones -- dz = gamma rstd (g - sum_all g / N_all - xhat sum_all(g xhat) / N_all) for this rank's positions.
+__global__ void conv1_bwd_finish_kernel(const double* Gsum, const double* Gglob, const double* moments, const float* w, int C, int KK,
+                                        double count, const double* count_dev, const float* gamma, const float* mean, const float* rstd,
+                                        int batch_stats, float* dw, float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
   const double* G = Gsum + (long long)c * (KK + 1);
-  const double sg = G[KK];
+  const double* Gg = (Gglob ? Gglob : Gsum) + (long long)c * (KK + 1);
+  const double sg = G[KK], sg_all = Gg[KK];
   if (!mean) {  // no BatchNorm: z = w.p + bias
     for (int k = 0; k < KK; ++k) dw[c * KK + k] = (float)G[k];
     if (dbeta) dbeta[c] = (float)sg;  // the bias gradient
     return;
   }
-  double sgz = 0.0;
-  for (int k = 0; k < KK; ++k) sgz += (double)w[c * KK + k] * G[k];
+  double sgz = 0.0, sgz_all = 0.0;
+  for (int k = 0; k < KK; ++k) {
+    sgz += (double)w[c * KK + k] * G[k];
+    sgz_all += (double)w[c * KK + k] * Gg[k];
+  }
   const double m = mean[c], rs = rstd[c], ga = gamma ? (double)gamma[c] : 1.0;
-  const double dg = rs * (sgz - m * sg);  // sum g * xhat
+  const double dg = rs * (sgz - m * sg);              // sum g * xhat over this rank's positions
+  const double dg_all = rs * (sgz_all - m * sg_all);  // ... over all ranks'
   if (dgamma) dgamma[c] = (float)dg;
   if (dbeta) dbeta[c] = (float)sg;
   const double* S = moments;
@@ -380,8 +391,8 @@ __global__ void conv1_bwd_finish_kernel(const double* Gsum, const double* moment
     if (batch_stats) {
       double swS = 0.0;
       for (int i = 0; i < KK; ++i) swS += (double)w[c * KK + i] * S[i * KK + k];
-      const double sxp = rs * (swS - m * P[k]);  // sum_pos xhat * p_k
-      v -= (sg / count) * P[k] + (dg / count) * sxp;
+      const double sxp = rs * (swS - m * P[k]);  // sum_pos xhat * p_k (this rank's positions)
+      v -= (sg_all / count) * P[k] + (dg_all / count) * sxp;
     }
     dw[c * KK + k] = (float)(ga * rs * v);
   }
@@ -548,11 +559,12 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* z, const T* 
 
 // forward finish from sums[0][c] = sum z, sums[1][c] = sum z^2 (float64): batch mean / biased variance -> scale, shift, saved
 // mean / rstd; running statistics updated in place
-__global__ void bn_stats_finish_kernel(const double* sums, int C, double count, const float* gamma, const float* beta, float eps,
-                                       float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
-                                       float* rstd) {
+__global__ void bn_stats_finish_kernel(const double* sums, int C, double count, const double* count_dev, const float* gamma,
+                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                       float* shift, float* mean, float* rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
   const double m = sums[c] / count;
   double var = sums[C + c] / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -569,24 +581,29 @@ __global__ void bn_stats_finish_kernel(const double* sums, int C, double count, 
 // backward finish from sums[0][c] = sum g, sums[1][c] = sum g*z: dgamma = sum g*xhat, dbeta = sum g and the per-column coefficients of
 // dz = ca*g + cb*z + cc
 //   batch statistics: dz = gamma*rstd * (g - sum g / N - xhat * dgamma / N);  fixed (running) statistics or no BatchNorm: dz = scale * g
-__global__ void bn_bwd_finish_kernel(const double* sums, int C, double count, const float* scale, const float* mean, const float* rstd,
-                                     int batch_stats, float* dgamma, float* dbeta, float* coef) {
+//   synchronised statistics: dgamma / dbeta from THIS rank's sums (`sums`), the coefficients from the sums of all ranks (`sums_all`, `count_dev`)
+__global__ void bn_bwd_finish_kernel(const double* sums, const double* sums_all, int C, double count, const double* count_dev,
+                                     const float* scale, const float* mean, const float* rstd, int batch_stats, float* dgamma, float* dbeta,
+                                     float* coef) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;
+  if (!sums_all) sums_all = sums;
   const double sg = sums[c], sgz = sums[C + c];
+  const double sg_all = sums_all[c], sgz_all = sums_all[C + c];
   const double a = (double)scale[c];  // gamma * rstd (or 1 without BatchNorm)
-  double dg = 0.0;
+  double dg_all = 0.0;
   if (mean) {
     const double m = mean[c], rs = rstd[c];
-    dg = rs * (sgz - m * sg);
-    if (dgamma) dgamma[c] = (float)dg;
+    dg_all = rs * (sgz_all - m * sg_all);
+    if (dgamma) dgamma[c] = (float)(rs * (sgz - m * sg));
   }
   if (dbeta) dbeta[c] = (float)sg;
   double cb = 0.0, cc = 0.0;
   if (mean && batch_stats) {
     const double m = mean[c], rs = rstd[c];
-    cb = -a * rs * dg / count;
-    cc = -a * sg / count - cb * m;
+    cb = -a * rs * dg_all / count;
+    cc = -a * sg_all / count - cb * m;
   }
   coef[c] = (float)a;
   coef[C + c] = (float)cb;
@@ -719,13 +736,13 @@ SC_API int sc_conv1_moments(const float* x, long long stride_b, long long stride
   return SC_OK;
 }
 
-SC_API int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const float* gamma, const float* beta,
-                              float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
-                              float* rstd, hipStream_t stream) {
+SC_API int sc_conv1_bn_coeffs(const double* moments, const float* w, int C, int KK, long long count, const double* count_dev,
+                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                              float* scale, float* shift, float* mean, float* rstd, hipStream_t stream) {
   SC_CHECK_ARG(moments && w && scale && shift && mean && rstd, "sc_conv1_bn_coeffs: null pointer");
   SC_CHECK_ARG(C >= 1 && KK >= 1 && KK <= MAX_TAPS && count >= 1, "sc_conv1_bn_coeffs: bad sizes C=%d KK=%d count=%lld", C, KK, count);
-  hipLaunchKernelGGL(conv1_bn_coeffs_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, moments, w, C, KK, (double)count, gamma, beta, eps,
-                     momentum, running_mean, running_var, scale, shift, mean, rstd);
+  hipLaunchKernelGGL(conv1_bn_coeffs_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, moments, w, C, KK, (double)count, count_dev, gamma,
+                     beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
   SC_LAUNCH_CHECK("conv1_bn_coeffs_kernel");
   return SC_OK;
 }
@@ -762,29 +779,25 @@ SC_API long long sc_conv1_bwd_workspace(int B, int Ti, int Fi, int To, int Fo, i
   return n * (long long)sizeof(double) + (long long)tiling(g).groups * n * (long long)sizeof(float);
 }
 
-SC_API int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
-                        int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act, float slope,
-                        const void* dy, const double* moments, const float* gamma, const float* mean, const float* rstd, int batch_stats,
-                        float* dw, float* dgamma, float* dbeta, void* workspace, long long ws_bytes, hipStream_t stream) {
-  SC_CHECK_ARG(x && w && scale && shift && dy && dw && workspace, "sc_conv1_bwd: null pointer");
-  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_conv1_bwd: dtype must be 0 (f32) or 1 (bf16)");
-  SC_CHECK_ARG(act >= 0 && act <= 2 && C >= 1, "sc_conv1_bwd: bad act %d / C %d", act, C);
-  SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_conv1_bwd: mean and rstd come together");
-  SC_CHECK_ARG(!(mean && batch_stats) || moments, "sc_conv1_bwd: batch statistics need the forward moments");
+SC_API int sc_conv1_bwd_reduce(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH,
+                               int KW, int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act,
+                               float slope, const void* dy, double* gsum, void* workspace, long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(x && w && scale && shift && dy && gsum && workspace, "sc_conv1_bwd_reduce: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_conv1_bwd_reduce: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(act >= 0 && act <= 2 && C >= 1, "sc_conv1_bwd_reduce: bad act %d / C %d", act, C);
   SC_GEO(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW);
   const int KK = KH * KW;
-  SC_CHECK_ARG(KK <= MAX_TAPS, "sc_conv1_bwd: at most %d taps", MAX_TAPS);
-  SC_CHECK_ARG(stride_t >= Fi && stride_b >= (long long)Ti * stride_t, "sc_conv1_bwd: strides too small");
-  SC_CHECK_ARG(ws_bytes >= sc_conv1_bwd_workspace(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW, C), "sc_conv1_bwd: workspace too small");
-  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_conv1_bwd: workspace must be 8-byte aligned");
+  SC_CHECK_ARG(KK <= MAX_TAPS, "sc_conv1_bwd_reduce: at most %d taps", MAX_TAPS);
+  SC_CHECK_ARG(stride_t >= Fi && stride_b >= (long long)Ti * stride_t, "sc_conv1_bwd_reduce: strides too small");
   const Tiling tl = tiling(g);
   const long long n = (long long)C * (KK + 1);
-  double* gsum = (double*)workspace;
-  float* partial = (float*)(gsum + n);
+  SC_CHECK_ARG(ws_bytes >= (long long)tl.groups * n * (long long)sizeof(float), "sc_conv1_bwd_reduce: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 4 == 0 && (uintptr_t)gsum % 8 == 0, "sc_conv1_bwd_reduce: misaligned workspace / gsum");
+  float* partial = (float*)workspace;
   const int CSp = (std::min(C, 256) + 3) & ~3;
   const int lanes = std::max(1, 256 / (CSp / 4));
   const size_t lds = tile_lds(g, tl) + (size_t)lanes * CSp * sizeof(float);
-  SC_CHECK_ARG(lds <= 60000, "sc_conv1_bwd: input rows + reduction scratch (%zu bytes) do not fit LDS", lds);
+  SC_CHECK_ARG(lds <= 60000, "sc_conv1_bwd_reduce: input rows + reduction scratch (%zu bytes) do not fit LDS", lds);
   const dim3 grid(tl.groups, sc_cdiv(C, 256));
 #define SC_LAUNCH_REDUCE(T, KKT)                                                                                                          \
   hipLaunchKernelGGL((conv1_bwd_reduce_kernel<T, KKT>), grid, dim3(256), lds, stream, x, stride_b, stride_t, g, w, C, scale, shift, act, slope, \
@@ -798,10 +811,37 @@ SC_API int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long
   SC_LAUNCH_CHECK("conv1_bwd_reduce_kernel");
   hipLaunchKernelGGL(sum_partials_kernel<float>, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, stream, (const float*)partial, tl.groups, n, gsum);
   SC_LAUNCH_CHECK("sum_partials_kernel");
-  hipLaunchKernelGGL(conv1_bwd_finish_kernel, dim3(sc_cdiv(C, 64)), dim3(64), 0, stream, (const double*)gsum, moments, w, C, KK,
-                     (double)B * To * Fo, gamma, mean, rstd, batch_stats, dw, dgamma, dbeta);
+  return SC_OK;
+}
+
+SC_API int sc_conv1_bwd_finish(const double* gsum, const double* gsum_all, const double* moments, const float* w, int C, int KK, long long count,
+                               const double* count_dev, const float* gamma, const float* mean, const float* rstd, int batch_stats, float* dw,
+                               float* dgamma, float* dbeta, hipStream_t stream) {
+  SC_CHECK_ARG(gsum && w && dw, "sc_conv1_bwd_finish: null pointer");
+  SC_CHECK_ARG(C >= 1 && KK >= 1 && KK <= MAX_TAPS && count >= 1, "sc_conv1_bwd_finish: bad sizes C=%d KK=%d count=%lld", C, KK, count);
+  SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_conv1_bwd_finish: mean and rstd come together");
+  SC_CHECK_ARG(!(mean && batch_stats) || moments, "sc_conv1_bwd_finish: batch statistics need the forward moments");
+  SC_CHECK_ARG((gsum_all == nullptr) == (count_dev == nullptr), "sc_conv1_bwd_finish: the sums of all ranks and their count come together");
+  hipLaunchKernelGGL(conv1_bwd_finish_kernel, dim3(sc_cdiv(C, 64)), dim3(64), 0, stream, gsum, gsum_all, moments, w, C, KK, (double)count,
+                     count_dev, gamma, mean, rstd, batch_stats, dw, dgamma, dbeta);
   SC_LAUNCH_CHECK("conv1_bwd_finish_kernel");
   return SC_OK;
+}
+
+SC_API int sc_conv1_bwd(int dtype, const float* x, long long stride_b, long long stride_t, int B, int Ti, int Fi, int To, int Fo, int KH, int KW,
+                        int SH, int SW, int PH, int PW, const float* w, int C, const float* scale, const float* shift, int act, float slope,
+                        const void* dy, const double* moments, const float* gamma, const float* mean, const float* rstd, int batch_stats,
+                        float* dw, float* dgamma, float* dbeta, void* workspace, long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(dw && workspace, "sc_conv1_bwd: null pointer");
+  SC_CHECK_ARG(ws_bytes >= sc_conv1_bwd_workspace(B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW, C) && ws_bytes > 0, "sc_conv1_bwd: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_conv1_bwd: workspace must be 8-byte aligned");
+  const long long n = (long long)C * (KH * KW + 1);
+  double* gsum = (double*)workspace;
+  int rc = sc_conv1_bwd_reduce(dtype, x, stride_b, stride_t, B, Ti, Fi, To, Fo, KH, KW, SH, SW, PH, PW, w, C, scale, shift, act, slope, dy, gsum,
+                               gsum + n, ws_bytes - n * (long long)sizeof(double), stream);
+  if (rc != SC_OK) return rc;
+  return sc_conv1_bwd_finish(gsum, nullptr, moments, w, C, KH * KW, (long long)B * To * Fo, nullptr, gamma, mean, rstd, batch_stats, dw, dgamma,
+                             dbeta, stream);
 }
 
 // ---- blocks with C_in > 1 ----------------------------------------------------------------------------------------------------------
@@ -857,33 +897,62 @@ SC_API long long sc_bn_workspace(long long M, int C) {  // [2][C] float64 sums, 
   return 2LL * C * (long long)sizeof(double) + (long long)slabs * 2 * C * (long long)sizeof(float);
 }
 
-SC_API int sc_bn_stats(int dtype, const void* z, long long M, int C, const float* gamma, const float* beta, float eps, float momentum,
-                       float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, void* workspace,
-                       long long ws_bytes, hipStream_t stream) {
-  SC_CHECK_ARG(z && scale && shift && mean && rstd && workspace, "sc_bn_stats: null pointer");
-  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_stats: dtype must be 0 (f32) or 1 (bf16)");
-  SC_CHECK_ARG(M >= 1 && C >= 1, "sc_bn_stats: bad sizes M=%lld C=%d", M, C);
-  SC_CHECK_ARG((uintptr_t)z % 16 == 0, "sc_bn_stats: z must be 16-byte aligned");
-  SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C), "sc_bn_stats: workspace too small");
-  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_stats: workspace must be 8-byte aligned");
+SC_API int sc_bn_sums(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, int act, float slope,
+                      double* sums, void* workspace, long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(z && sums && workspace, "sc_bn_sums: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_sums: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 3, "sc_bn_sums: bad sizes M=%lld C=%d act=%d", M, C, act);
+  SC_CHECK_ARG(!dy || (scale && shift), "sc_bn_sums: the backward sums need scale and shift");
+  SC_CHECK_ARG((uintptr_t)z % 16 == 0 && (!dy || (uintptr_t)dy % 16 == 0), "sc_bn_sums: z / dy must be 16-byte aligned");
   long long rps;
   const int slabs = col_slabs(M, &rps);
-  double* sums = (double*)workspace;
-  float* partial = (float*)(sums + 2LL * C);
+  SC_CHECK_ARG(ws_bytes >= (long long)slabs * 2 * C * (long long)sizeof(float), "sc_bn_sums: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 4 == 0 && (uintptr_t)sums % 8 == 0, "sc_bn_sums: misaligned workspace / sums");
+  float* partial = (float*)workspace;
   const dim3 grid(sc_cdiv(C, 128), slabs);
-  if (dtype == 0)
-    hipLaunchKernelGGL((bn_colreduce_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)z, (const float*)nullptr, M, C, nullptr,
-                       nullptr, 0, 0.f, rps, partial);
-  else
-    hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 0>), grid, dim3(256), 0, stream, (const unsigned short*)z,
-                       (const unsigned short*)nullptr, M, C, nullptr, nullptr, 0, 0.f, rps, partial);
-  SC_LAUNCH_CHECK("bn_colreduce_kernel<0>");
+  if (!dy) {
+    if (dtype == 0)
+      hipLaunchKernelGGL((bn_colreduce_kernel<float, 0>), grid, dim3(256), 0, stream, (const float*)z, (const float*)nullptr, M, C, nullptr,
+                         nullptr, 0, 0.f, rps, partial);
+    else
+      hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 0>), grid, dim3(256), 0, stream, (const unsigned short*)z,
+                         (const unsigned short*)nullptr, M, C, nullptr, nullptr, 0, 0.f, rps, partial);
+    SC_LAUNCH_CHECK("bn_colreduce_kernel<0>");
+  } else {
+    if (dtype == 0)
+      hipLaunchKernelGGL((bn_colreduce_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)z, (const float*)dy, M, C, scale, shift, act,
+                         slope, rps, partial);
+    else
+      hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 1>), grid, dim3(256), 0, stream, (const unsigned short*)z, (const unsigned short*)dy,
+                         M, C, scale, shift, act, slope, rps, partial);
+    SC_LAUNCH_CHECK("bn_colreduce_kernel<1>");
+  }
   hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sc_cdiv(2 * C, 32)), dim3(1024), 0, stream, (const float*)partial, slabs, 2LL * C, sums);
   SC_LAUNCH_CHECK("sum_partials_kernel");
-  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const double*)sums, C, (double)M, gamma, beta, eps,
+  return SC_OK;
+}
+
+SC_API int sc_bn_stats_finish(const double* sums, int C, long long count, const double* count_dev, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                              hipStream_t stream) {
+  SC_CHECK_ARG(sums && scale && shift && mean && rstd, "sc_bn_stats_finish: null pointer");
+  SC_CHECK_ARG(C >= 1 && count >= 1, "sc_bn_stats_finish: bad sizes C=%d count=%lld", C, count);
+  hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, sums, C, (double)count, count_dev, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, mean, rstd);
   SC_LAUNCH_CHECK("bn_stats_finish_kernel");
   return SC_OK;
+}
+
+SC_API int sc_bn_stats(int dtype, const void* z, long long M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, void* workspace,
+                       long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(workspace, "sc_bn_stats: null pointer");
+  SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C) && M >= 1 && C >= 1, "sc_bn_stats: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_stats: workspace must be 8-byte aligned");
+  double* sums = (double*)workspace;
+  int rc = sc_bn_sums(dtype, z, nullptr, M, C, nullptr, nullptr, 0, 0.f, sums, sums + 2LL * C, ws_bytes - 2LL * C * (long long)sizeof(double), stream);
+  if (rc != SC_OK) return rc;
+  return sc_bn_stats_finish(sums, C, M, nullptr, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd, stream);
 }
 
 SC_API int sc_bn_act_fwd(int dtype, const void* z, long long M, int C, const float* scale, const float* shift, int act, float slope, void* y,
@@ -904,34 +973,24 @@ SC_API int sc_bn_act_fwd(int dtype, const void* z, long long M, int C, const flo
   return SC_OK;
 }
 
-SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, const float* mean,
-                         const float* rstd, int batch_stats, int act, float slope, void* dz, float* dgamma, float* dbeta, void* workspace,
-                         long long ws_bytes, hipStream_t stream) {
-  SC_CHECK_ARG(z && dy && scale && shift && dz && workspace, "sc_bn_act_bwd: null pointer");
-  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_act_bwd: dtype must be 0 (f32) or 1 (bf16)");
-  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 3, "sc_bn_act_bwd: bad sizes M=%lld C=%d act=%d", M, C, act);
-  SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_bn_act_bwd: mean and rstd come together");
-  SC_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dz % 16 == 0), "sc_bn_act_bwd: buffers must be 16-byte aligned");
-  SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C) + 3LL * C * (long long)sizeof(float), "sc_bn_act_bwd: workspace too small");
-  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_act_bwd: workspace must be 8-byte aligned");
-  long long rps;
-  const int slabs = col_slabs(M, &rps);
-  double* sums = (double*)workspace;
-  float* partial = (float*)(sums + 2LL * C);
-  float* coef = partial + (long long)slabs * 2 * C;
-  const dim3 grid(sc_cdiv(C, 128), slabs);
-  if (dtype == 0)
-    hipLaunchKernelGGL((bn_colreduce_kernel<float, 1>), grid, dim3(256), 0, stream, (const float*)z, (const float*)dy, M, C, scale, shift, act,
-                       slope, rps, partial);
-  else
-    hipLaunchKernelGGL((bn_colreduce_kernel<unsigned short, 1>), grid, dim3(256), 0, stream, (const unsigned short*)z, (const unsigned short*)dy,
-                       M, C, scale, shift, act, slope, rps, partial);
-  SC_LAUNCH_CHECK("bn_colreduce_kernel<1>");
-  hipLaunchKernelGGL(sum_partials_kernel<float>, dim3(sc_cdiv(2 * C, 32)), dim3(1024), 0, stream, (const float*)partial, slabs, 2LL * C, sums);
-  SC_LAUNCH_CHECK("sum_partials_kernel");
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, (const double*)sums, C, (double)M, scale, mean, rstd,
-                     batch_stats, dgamma, dbeta, coef);
+SC_API int sc_bn_bwd_finish(const double* sums, const double* sums_all, int C, long long count, const double* count_dev, const float* scale,
+                            const float* mean, const float* rstd, int batch_stats, float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
+  SC_CHECK_ARG(sums && scale && coef, "sc_bn_bwd_finish: null pointer");
+  SC_CHECK_ARG(C >= 1 && count >= 1, "sc_bn_bwd_finish: bad sizes C=%d count=%lld", C, count);
+  SC_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "sc_bn_bwd_finish: mean and rstd come together");
+  SC_CHECK_ARG((sums_all == nullptr) == (count_dev == nullptr), "sc_bn_bwd_finish: the sums of all ranks and their count come together");
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(sc_cdiv(C, 128)), dim3(128), 0, stream, sums, sums_all, C, (double)count, count_dev, scale, mean,
+                     rstd, batch_stats, dgamma, dbeta, coef);
   SC_LAUNCH_CHECK("bn_bwd_finish_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_bn_bwd_apply(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, const float* coef,
+                           int act, float slope, void* dz, hipStream_t stream) {
+  SC_CHECK_ARG(z && dy && scale && shift && coef && dz, "sc_bn_bwd_apply: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_bn_bwd_apply: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(M >= 1 && C >= 1 && act >= 0 && act <= 3, "sc_bn_bwd_apply: bad sizes M=%lld C=%d act=%d", M, C, act);
+  SC_CHECK_ARG(((uintptr_t)z % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dz % 16 == 0), "sc_bn_bwd_apply: buffers must be 16-byte aligned");
   long long rpb;
   const unsigned g2 = apply_grid(M, C, &rpb);
   if (dtype == 0)
@@ -942,4 +1001,22 @@ SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, 
                        M, C, scale, shift, coef, act, slope, (unsigned short*)dz, rpb);
   SC_LAUNCH_CHECK("bn_apply_kernel<1>");
   return SC_OK;
+}
+
+SC_API int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, int C, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, int batch_stats, int act, float slope, void* dz, float* dgamma, float* dbeta, void* workspace,
+                         long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(workspace && M >= 1 && C >= 1, "sc_bn_act_bwd: null pointer / bad sizes");
+  SC_CHECK_ARG(ws_bytes >= sc_bn_workspace(M, C) + 3LL * C * (long long)sizeof(float), "sc_bn_act_bwd: workspace too small");
+  SC_CHECK_ARG((uintptr_t)workspace % 8 == 0, "sc_bn_act_bwd: workspace must be 8-byte aligned");
+  long long rps;
+  const int slabs = col_slabs(M, &rps);
+  double* sums = (double*)workspace;
+  float* partial = (float*)(sums + 2LL * C);
+  float* coef = partial + (long long)slabs * 2 * C;
+  int rc = sc_bn_sums(dtype, z, dy, M, C, scale, shift, act, slope, sums, partial, (long long)slabs * 2 * C * (long long)sizeof(float), stream);
+  if (rc != SC_OK) return rc;
+  rc = sc_bn_bwd_finish(sums, nullptr, C, M, nullptr, scale, mean, rstd, batch_stats, dgamma, dbeta, coef, stream);
+  if (rc != SC_OK) return rc;
+  return sc_bn_bwd_apply(dtype, z, dy, M, C, scale, shift, coef, act, slope, dz, stream);
 }

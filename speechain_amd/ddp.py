@@ -11,9 +11,9 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): a 312 MB fp32 gradient set
 ~25-50 MB bucket is hidden behind the remaining backward compute.
 Works with any process group (``nccl`` = RCCL on GPUs; ``gloo`` on CPU for the tests).
 """
-from typing import Iterable, List
-
+import contextlib
 import os
+from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
@@ -83,6 +83,11 @@ class GradBucketReducer:
             self._make_bucket(cur)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._pending = []
+        # gradient accumulation (no_sync): micro-steps whose gradients stay on this rank.  With gradient sinks the kernels OVERWRITE their
+        # slots, so a held micro-step's buckets are added to accumulators of the same layout, which are folded back into the buckets right
+        # before they are reduced (or, on one rank, in wait()).  Without sinks autograd accumulates into the slot views by itself.
+        self._hold = False
+        self._acc, self._acc_live = None, False
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
@@ -104,7 +109,7 @@ class GradBucketReducer:
                 from speechain_amd.functional import GradSinks
 
                 GradSinks.register(p, flat, o)
-        self.buckets.append(dict(params=plist, flat=flat, ready=0, views=views, offsets=offsets,
+        self.buckets.append(dict(params=plist, flat=flat, ready=0, views=views, offsets=offsets, id=len(self.buckets),
                                  index={id(p): i for i, p in enumerate(plist)}))
 
     def _make_hook(self, bi):
@@ -120,8 +125,17 @@ class GradBucketReducer:
                 self._launch(b)
         return hook
 
+    def _fold(self, b):
+        """Adds what earlier micro-steps of this update left in the accumulator to a bucket whose slots now hold the last micro-step's
+        gradients (once per update)."""
+        if self._acc_live and not b.get("folded", False):
+            b["flat"].add_(self._acc[b["id"]])
+            b["folded"] = True
+
     def _launch(self, b):
-        if not self.multi:
+        if self._hold:  # a micro-step inside no_sync(): nothing leaves this rank
+            return
+        if not self.multi:  # (one rank: accumulators are folded in wait(), after every deferred gradient launch of backward)
             return
         if self.cuda and torch.cuda.is_current_stream_capturing():
             # Backward is being captured into a hipGraph: a collective issued from a hook would fork the side stream off the
@@ -145,6 +159,7 @@ class GradBucketReducer:
 
                 _LnFinish.flush()
                 _WgradQueue.flush()  # (weight gradients deferred to one grouped launch: they must be in the slots now)
+            self._fold(b)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
@@ -152,6 +167,7 @@ class GradBucketReducer:
                 work = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._pending.append(work)
         else:
+            self._fold(b)
             work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._pending.append((work, b["flat"]))
 
@@ -201,11 +217,12 @@ class GradBucketReducer:
         self._launch(b)
 
     def broadcast_parameters(self, src: int = 0):
-        """One-off parameter (and nothing else) broadcast at start-up."""
+        """One-off parameter (and nothing else) broadcast at start-up: one collective per flat parameter buffer (nine for the 78 M-parameter
+        ASR model) instead of one per tensor; parameters are moved into the flat buffers for it (see ``flatten_parameters``)."""
         if not self.multi:
             return
-        for p in self.params:
-            dist.broadcast(p.data, src=src, group=self.pg)
+        for flat in self.flatten_parameters():
+            dist.broadcast(flat, src=src, group=self.pg)
 
     def settle(self):
         """Public form of the step below for callers that capture backward into a hipGraph: called INSIDE the captured region,
@@ -234,6 +251,9 @@ class GradBucketReducer:
         for b in self.buckets:
             if b["ready"] != len(b["params"]) and b["ready"] != -1:
                 self._launch(b)
+        if not self.multi:
+            for b in self.buckets:
+                self._fold(b)
         for w in self._pending:
             if self.cuda:
                 w.wait()
@@ -245,11 +265,53 @@ class GradBucketReducer:
         for b in self.buckets:
             b["ready"] = 0
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """A micro-step of gradient accumulation: ``with reducer.no_sync(): loss.backward()`` keeps this backward pass's gradients on the
+        rank, exactly like ``DistributedDataParallel.no_sync`` in the reference's ``OptimScheduler.step`` (speechain/optim_sche/abs.py:180-188:
+        every step but the last of ``accum_grad`` runs under it, the loss being divided by ``accum_grad`` by the caller, :205-207).  The last
+        micro-step runs outside the context; its buckets leave as the SUM of all micro-steps since ``zero_grad()``.  Eager steps only (a
+        captured step replays one fixed micro-step)."""
+        assert not (self.cuda and torch.cuda.is_current_stream_capturing()), "no_sync(): gradient accumulation is not captured into hipGraphs"
+        self._hold = True
+        try:
+            yield
+        finally:
+            self._hold = False
+            self._stash()
+
+    def _stash(self):
+        if self.use_sinks:
+            from speechain_amd.functional import GradSinks, _LnFinish, _WgradQueue
+
+            if self.cuda:
+                _LnFinish.flush()
+                _WgradQueue.flush()
+            self._settle()
+            if self._acc is None:
+                self._acc = [torch.zeros_like(b["flat"]) for b in self.buckets]
+            with torch.no_grad():
+                for a, b in zip(self._acc, self.buckets):
+                    if self._acc_live:
+                        a.add_(b["flat"])
+                    else:
+                        a.copy_(b["flat"])
+            self._acc_live = True
+            GradSinks.begin_step()  # the next micro-step's kernels write the slots afresh
+            for b in self.buckets:
+                for p in b["params"]:
+                    p.grad = None
+        for b in self.buckets:  # (without sinks autograd keeps adding into the slot views: nothing to move)
+            b["ready"] = 0
+
     def zero_grad(self):
         """Start of a step.  With gradient sinks the kernels overwrite their slots, so nothing is zeroed: ``param.grad`` is
         dropped (autograd then adopts the slot view a kernel returns instead of adding into it).  Without sinks the flat
         buckets are zeroed and gradients stay views into them."""
         self.step_stream = torch.cuda.current_stream(self.device) if self.cuda else None  # (the stream the step's main path runs on)
+        self._acc_live = False
+        for b in self.buckets:
+            b["folded"] = False
         if self.use_sinks:
             from speechain_amd.functional import GradSinks
 

@@ -1529,13 +1529,49 @@ def _sink_or_new(params, shape, device):
     return sink.view(shape) if sink is not None else torch.empty(shape, dtype=torch.float32, device=device)
 
 
+class _RankSums:
+    """The exchange step of ``torch.nn.SyncBatchNorm``: per-rank float64 sum vectors (and position counts) summed over a process group.
+    The reference turns every BatchNorm of a DDP model into its synchronised form (speechain/runner.py:303-310 ``enable_syncbatchnorm``,
+    default True; :1856-1858), so under DDP the prenet / postnet normalise with the statistics of the batches of ALL ranks.  Here the HIP
+    kernels produce the rank's sums, one small all-reduce (C-sized, on the current stream) makes them global, and the finish kernels read
+    both (include/speechain_amd.h, "Synchronised batch statistics")."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def sum_with_count(self, local: torch.Tensor, count: int):
+        buf = torch.cat([local.reshape(-1), torch.full((1,), float(count), dtype=torch.float64, device=local.device)])
+        torch.distributed.all_reduce(buf, group=self.group)
+        return buf[:-1], buf[-1:]
+
+    def sum(self, local: torch.Tensor):
+        buf = local.clone()
+        torch.distributed.all_reduce(buf, group=self.group)
+        return buf
+
+    @staticmethod
+    def of(bn, use_batch: bool, training: bool):
+        """The exchange object for a BatchNorm module, or None: only a ``SyncBatchNorm`` (what ``convert_sync_batchnorm`` leaves in place of
+        the ``nn.BatchNorm*d`` holders) in training mode with a live process group of more than one rank synchronises, as torch's does."""
+        if not (isinstance(bn, torch.nn.SyncBatchNorm) and use_batch and training):
+            return None
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            return None
+        group = bn.process_group
+        if dist.get_world_size(group) < 2 and _os.environ.get("SC_DDP_FORCE_COLLECTIVES", "0") != "1":
+            return None
+        return _RankSums(group)
+
+
 class _ConvFirst(torch.autograd.Function):
     """Conv2d(1, C, kernel, stride, padding) [+ BatchNorm2d] [+ activation] on a (B, T, F) float32 image -> (B, To, Fo, C).
     Training-mode BatchNorm takes its statistics from the patch moments (no pre-normalisation tensor exists); the running
     statistics are updated in place, as torch does."""
 
     @staticmethod
-    def forward(ctx, feat, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps, dtype):
+    def forward(ctx, feat, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps, dtype, sync=None):
         require_gpu(feat, "the Conv2d prenet")
         (kh, kw), (sh, sw), (ph, pw) = geom
         x = feat.detach()
@@ -1554,8 +1590,10 @@ class _ConvFirst(torch.autograd.Function):
             moments = torch.empty(KK * KK + KK, dtype=torch.float64, device=dev)
             lib.call("sc_conv1_moments", _p(x), x.stride(0), x.stride(1), *g6, _p(moments), _p(ws), ws.numel(), stream())
             scale, shift, mean, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
-            lib.call("sc_conv1_bn_coeffs", _p(moments), _p(w2), C, KK, B * To * Fo, _p(gamma.detach()), _p(beta.detach()), float(eps),
-                     float(momentum), _p(rm), _p(rv), _p(scale), _p(shift), _p(mean), _p(rstd), stream())
+            # synchronised statistics: the moments of all ranks' patches and their count (this rank's moments are kept for backward)
+            mom_all, count_all = sync.sum_with_count(moments, B * To * Fo) if sync is not None else (moments, None)
+            lib.call("sc_conv1_bn_coeffs", _p(mom_all), _p(w2), C, KK, B * To * Fo, _p(count_all), _p(gamma.detach()), _p(beta.detach()),
+                     float(eps), float(momentum), _p(rm), _p(rv), _p(scale), _p(shift), _p(mean), _p(rstd), stream())
         elif bn:
             scale, shift, mean, rstd = _bn_eval_coeffs(gamma, beta, rm, rv, eps)
         else:
@@ -1567,6 +1605,7 @@ class _ConvFirst(torch.autograd.Function):
         ctx.save_for_backward(x, w, scale, shift, moments, gamma, mean, rstd)
         ctx.params = (w, bias, gamma, beta)
         ctx.meta = (g6, act, slope, bn, bn and training)
+        ctx.sync = (sync, count_all) if (sync is not None and bn and training) else None
         return y
 
     @staticmethod
@@ -1586,10 +1625,19 @@ class _ConvFirst(torch.autograd.Function):
         dgamma = _sink_or_new([pg], (C,), dev) if bn else None
         dbeta = _sink_or_new([pbe], (C,), dev) if bn else (_sink_or_new([pb], (C,), dev) if pb is not None else None)
         ws = torch.empty(lib.value("sc_conv1_bwd_workspace", *g6, C), dtype=torch.uint8, device=dev)
-        lib.call("sc_conv1_bwd", dcode(dy), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope), _p(dy),
-                 _p(moments), _p(gamma.detach()) if bn else None, _p(mean), _p(rstd), 1 if batch_stats else 0, _p(dw), _p(dgamma), _p(dbeta),
-                 _p(ws), ws.numel(), stream())
-        return (None, dw.view_as(w), None if bn else dbeta, dgamma, dbeta if bn else None) + (None,) * 9
+        if ctx.sync is None:
+            lib.call("sc_conv1_bwd", dcode(dy), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope), _p(dy),
+                     _p(moments), _p(gamma.detach()) if bn else None, _p(mean), _p(rstd), 1 if batch_stats else 0, _p(dw), _p(dgamma), _p(dbeta),
+                     _p(ws), ws.numel(), stream())
+        else:  # reduce -> all-reduce of (sum g.patch, sum g) -> finish with this rank's and all ranks' sums
+            sync, count_all = ctx.sync
+            gsum = torch.empty(C * (KK + 1), dtype=torch.float64, device=dev)
+            lib.call("sc_conv1_bwd_reduce", dcode(dy), _p(x), x.stride(0), x.stride(1), *g6, _p(w2), C, _p(scale), _p(shift), act, float(slope),
+                     _p(dy), _p(gsum), _p(ws), ws.numel(), stream())
+            gsum_all = sync.sum(gsum)
+            lib.call("sc_conv1_bwd_finish", _p(gsum), _p(gsum_all), _p(moments), _p(w2), C, KK, B * To * g6[4], _p(count_all), _p(gamma.detach()),
+                     _p(mean), _p(rstd), 1, _p(dw), _p(dgamma), _p(dbeta), stream())
+        return (None, dw.view_as(w), None if bn else dbeta, dgamma, dbeta if bn else None) + (None,) * 10
 
 
 class _ConvNext(torch.autograd.Function):
@@ -1597,7 +1645,7 @@ class _ConvNext(torch.autograd.Function):
     im2col -> one GEMM against Wm[c_out][(kh, kw, c_in)] -> column statistics -> normalise + activation."""
 
     @staticmethod
-    def forward(ctx, a, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps):
+    def forward(ctx, a, w, bias, gamma, beta, rm, rv, geom, act, slope, training, momentum, eps, sync=None):
         require_gpu(a, "the Conv2d prenet")
         (kh, kw), (sh, sw), (ph, pw) = geom
         a = a if a.is_contiguous() else a.contiguous()
@@ -1618,8 +1666,16 @@ class _ConvNext(torch.autograd.Function):
         if bn and training:
             scale, shift, mean, rstd = (torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(4))
             ws = torch.empty(lib.value("sc_bn_workspace", M, Cout), dtype=torch.uint8, device=dev)
-            lib.call("sc_bn_stats", code, _p(z), M, Cout, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum), _p(rm), _p(rv),
-                     _p(scale), _p(shift), _p(mean), _p(rstd), _p(ws), ws.numel(), stream())
+            if sync is None:
+                lib.call("sc_bn_stats", code, _p(z), M, Cout, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum), _p(rm), _p(rv),
+                         _p(scale), _p(shift), _p(mean), _p(rstd), _p(ws), ws.numel(), stream())
+            else:  # column sums -> all-reduce (sum z, sum z^2, rows) -> statistics of the batches of all ranks
+                sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+                lib.call("sc_bn_sums", code, _p(z), None, M, Cout, None, None, 0, 0.0, _p(sums), _p(ws), ws.numel(), stream())
+                sums_all, count_all = sync.sum_with_count(sums, M)
+                lib.call("sc_bn_stats_finish", _p(sums_all), Cout, M, _p(count_all), _p(gamma.detach()), _p(beta.detach()), float(eps),
+                         float(momentum), _p(rm), _p(rv), _p(scale), _p(shift), _p(mean), _p(rstd), stream())
+                ctx.sync = (sync, count_all)
         elif bn:
             scale, shift, mean, rstd = _bn_eval_coeffs(gamma, beta, rm, rv, eps)
         else:
@@ -1633,6 +1689,8 @@ class _ConvNext(torch.autograd.Function):
         ctx.save_for_backward(col, z, w, scale, shift, mean, rstd)
         ctx.params = (w, bias, gamma, beta)
         ctx.meta = (g, act, slope, bn, bn and training)
+        if not (bn and training and sync is not None):
+            ctx.sync = None
         return y.view(B, To, Fo, Cout)
 
     @staticmethod
@@ -1652,8 +1710,18 @@ class _ConvNext(torch.autograd.Function):
             if bn:
                 dgamma, dbeta = _sink_or_new([pg], (Cout,), dev), _sink_or_new([pbe], (Cout,), dev)
             ws = torch.empty(lib.value("sc_bn_workspace", M, Cout) + 12 * Cout, dtype=torch.uint8, device=dev)
-            lib.call("sc_bn_act_bwd", code, _p(z), _p(dy2), M, Cout, _p(scale), _p(shift), _p(mean), _p(rstd), 1 if batch_stats else 0, act,
-                     float(slope), _p(dz), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), stream())
+            if ctx.sync is None:
+                lib.call("sc_bn_act_bwd", code, _p(z), _p(dy2), M, Cout, _p(scale), _p(shift), _p(mean), _p(rstd), 1 if batch_stats else 0, act,
+                         float(slope), _p(dz), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), stream())
+            else:  # (sum g, sum g z) -> all-reduce -> coefficients of dz from all ranks' sums, dgamma / dbeta from this rank's
+                sync, count_all = ctx.sync
+                sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+                coef = torch.empty(3 * Cout, dtype=torch.float32, device=dev)
+                lib.call("sc_bn_sums", code, _p(z), _p(dy2), M, Cout, _p(scale), _p(shift), act, float(slope), _p(sums), _p(ws), ws.numel(), stream())
+                sums_all = sync.sum(sums)
+                lib.call("sc_bn_bwd_finish", _p(sums), _p(sums_all), Cout, M, _p(count_all), _p(scale), _p(mean), _p(rstd), 1, _p(dgamma),
+                         _p(dbeta), _p(coef), stream())
+                lib.call("sc_bn_bwd_apply", code, _p(z), _p(dy2), M, Cout, _p(scale), _p(shift), _p(coef), act, float(slope), _p(dz), stream())
         else:
             dz = dy2
         side = _Side(z)
@@ -1675,7 +1743,7 @@ class _ConvNext(torch.autograd.Function):
             lib.call("sc_col2im", code, _p(dcol), *g, _p(da), stream())
         side.join()
         dw = dWm.view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
-        return (da, dw, dbias, dgamma, dbeta) + (None,) * 8
+        return (da, dw, dbias, dgamma, dbeta) + (None,) * 9
 
 
 class _Dropout(torch.autograd.Function):
@@ -1714,9 +1782,10 @@ def conv_block(x, conv: torch.nn.Conv2d, bn: Optional[torch.nn.BatchNorm2d], act
             bn.num_batches_tracked += 1
     else:
         args, mom, eps = (None, None, None, None), 0.0, 0.0
+    sync = _RankSums.of(bn, use_batch, training)  # (a SyncBatchNorm holder under a live process group: statistics over all ranks)
     if first:
-        return _ConvFirst.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps, compute_dtype())
-    return _ConvNext.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps)
+        return _ConvFirst.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps, compute_dtype(), sync)
+    return _ConvNext.apply(x, conv.weight, conv.bias, *args, geom, PACT[activation], slope, use_batch, mom, eps, sync)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
