@@ -920,3 +920,48 @@ def speech2linear_recover_post(wav: Tensor, feat_len: Tensor, hop: int, preemph:
     for i in range(len(wav_len)):
         wav[i, wav_len[i]:] = 0
     return wav.unsqueeze(-1), wav_len
+
+
+# --------------------------------------------------------------------------------------------------
+# speaker embeddings of the TTS decoder   speechain/module/prenet/spk_embed.py:7-230; used at decoder/nar_tts.py:257-263
+# --------------------------------------------------------------------------------------------------
+
+def speaker_embed(P: Dict[str, Tensor], prefix: str, enc_output: Tensor, spk_ids: Optional[Tensor] = None, spk_feat: Optional[Tensor] = None,
+                  dec_input: Optional[Tensor] = None, spk_emb_comb: str = "concat", dec_comb: bool = False, encdec_same_proj: bool = True):
+    """SpeakerEmbedPrenet.forward (:104-153) followed by combine_spk_feat (:155-227).  Which branches exist is read off the parameters, as the
+    module's ``hasattr`` checks do: ``spk_lookup.embed.weight`` (closed-set table, row 0 = padding), ``pre_add_proj_lookup`` /
+    ``pre_add_proj_pretrain`` (only with 'add' and a dimension other than d_model), ``final_proj_enc`` and ``final_proj_dec``.
+    Both vectors are L2-normalised (F.normalize, eps 1e-12) before they are combined; with 'concat' the pretrained vector comes first, then
+    the lookup one (:204-213).  Returns (spk_feat_lookup, spk_feat, enc_output, dec_input)."""
+    look = None
+    if prefix + "spk_lookup.embed.weight" in P:
+        look = F.embedding(spk_ids, P[prefix + "spk_lookup.embed.weight"], padding_idx=0)
+        if prefix + "pre_add_proj_lookup.weight" in P:
+            look = F.linear(look, P[prefix + "pre_add_proj_lookup.weight"], P[prefix + "pre_add_proj_lookup.bias"])
+        look = F.normalize(look, dim=-1)
+    pre = None
+    if spk_feat is not None:
+        pre = spk_feat
+        if prefix + "pre_add_proj_pretrain.weight" in P:
+            pre = F.linear(pre, P[prefix + "pre_add_proj_pretrain.weight"], P[prefix + "pre_add_proj_pretrain.bias"])
+        pre = F.normalize(pre, dim=-1)
+    pre3 = None if pre is None else (pre.unsqueeze(1) if pre.dim() == 2 else pre)
+    look3 = None if look is None else (look.unsqueeze(1) if look.dim() == 2 else look)
+
+    def combine(tgt, name):
+        if spk_emb_comb == "add":
+            if pre3 is not None:
+                tgt = tgt + pre3
+            if look3 is not None:
+                tgt = tgt + look3
+        else:
+            if pre3 is not None:
+                tgt = torch.cat([tgt, pre3.expand(-1, tgt.size(1), -1)], dim=-1)
+            if look3 is not None:
+                tgt = torch.cat([tgt, look3.expand(-1, tgt.size(1), -1)], dim=-1)
+        return F.linear(tgt, P[prefix + name + ".weight"], P[prefix + name + ".bias"])
+
+    enc_output = combine(enc_output, "final_proj_enc")
+    if dec_comb:
+        dec_input = combine(dec_input, "final_proj_enc" if encdec_same_proj else "final_proj_dec")
+    return look, pre, enc_output, dec_input

@@ -6,8 +6,9 @@ What runs where: the frontend, the three normalisations, the predictors, the dec
 drop-ins of this package; the two pieces of the reference that are Python loops over the batch become one launch each (csrc/tts.hip):
 the expansion of the token rows by their durations (:439-472) and ``average_scalar_by_duration`` (:150-204, a (B, L, T) index cube
 there).  Lengths and durations are (B,)- / (B, L)-sized device arithmetic with the reference's formulas.  Speaker embeddings
-(``spk_emb``) are outside this path and rejected."""
+(``spk_emb``: multi-speaker recipes, nar_tts.py:42-52, :257-263) go through ``speechain_amd.module.prenet.spk_embed.SpeakerEmbedPrenet``."""
 import copy
+import warnings
 from typing import Dict
 
 import torch
@@ -15,6 +16,7 @@ import torch
 from speechain_amd import functional as Fn
 from speechain_amd.module.abs import Module
 from speechain_amd.module.norm.feat_norm import FeatureNormalization
+from speechain_amd.module.prenet.spk_embed import SpeakerEmbedPrenet
 from speechain_amd.utilbox.import_util import import_class
 from speechain_amd.utilbox.train_util import make_len_from_mask, make_mask_from_len
 
@@ -23,9 +25,15 @@ class FastSpeech2Decoder(Module):
     def module_init(self, decoder: Dict, postnet: Dict, pitch_predictor: Dict, energy_predictor: Dict, duration_predictor: Dict,
                     spk_emb: Dict = None, feat_frontend: Dict = None, feat_normalize: Dict or bool = True, pitch_normalize: Dict or bool = True,
                     energy_normalize: Dict or bool = True, reduction_factor: int = 1):
-        if spk_emb is not None:
-            raise NotImplementedError("speechain_amd FastSpeech2Decoder: speaker embeddings (spk_emb) are outside the accelerated path")
         self.reduction_factor = reduction_factor
+        if spk_emb is not None:  # (nar_tts.py:42-52: d_model is forced to the decoder's input size)
+            spk_emb = copy.deepcopy(spk_emb)
+            if "d_model" in spk_emb.keys() and spk_emb["d_model"] != self.input_size:
+                warnings.warn(f"Your input d_model ({spk_emb['d_model']}) is different from the one automatically "
+                              f"generated during model initialization ({self.input_size})."
+                              f"Currently, the automatically generated one is used.")
+            spk_emb["d_model"] = self.input_size
+            self.spk_emb = SpeakerEmbedPrenet(**spk_emb)
         decoder, postnet, feat_frontend = copy.deepcopy(decoder), copy.deepcopy(postnet), copy.deepcopy(feat_frontend)
 
         def build(conf, **forced):
@@ -123,8 +131,9 @@ class FastSpeech2Decoder(Module):
                 energy: torch.Tensor = None, energy_len: torch.Tensor = None, spk_feat: torch.Tensor = None, spk_ids: torch.Tensor = None,
                 epoch: int = None, min_frame_num: int = None, max_frame_num: int = None, duration_alpha: torch.Tensor = None,
                 energy_alpha: torch.Tensor = None, pitch_alpha: torch.Tensor = None, _targets: Dict = None):
-        if spk_feat is not None or spk_ids is not None:
-            raise NotImplementedError("speechain_amd FastSpeech2Decoder: speaker features / ids are outside the accelerated path")
+        if hasattr(self, "spk_emb"):  # (nar_tts.py:257-263) speaker vectors into the encoded text, before everything else reads it
+            spk_feat_lookup, spk_feat = self.spk_emb(spk_ids=spk_ids, spk_feat=spk_feat)
+            enc_text, _ = self.spk_emb.combine_spk_feat(spk_feat=spk_feat, spk_feat_lookup=spk_feat_lookup, enc_output=enc_text)
         tg = _targets if _targets is not None else self.prepare_targets(
             duration=duration, duration_len=duration_len, pitch=pitch, pitch_len=pitch_len, feat=feat, feat_len=feat_len, energy=energy,
             energy_len=energy_len, spk_ids=spk_ids, epoch=epoch, min_frame_num=min_frame_num, max_frame_num=max_frame_num,

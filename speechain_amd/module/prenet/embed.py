@@ -16,5 +16,5 @@ class EmbedPrenet(Module):
         self.embed = torch.nn.Embedding(num_embeddings=vocab_size, embedding_dim=embedding_dim, padding_idx=padding_idx)
 
     def forward(self, text: torch.Tensor):
-        e = Fn.embedding(self.embed.weight, text, self.padding_idx) if text.is_cuda else self.embed(text)
+        e = Fn.embedding(self.embed.weight, text, self.padding_idx)  # (device tensors only, like every module here: no CPU path)
         return e * math.sqrt(self.embedding_dim) if self.scale else e

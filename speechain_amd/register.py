@@ -32,6 +32,7 @@ OVERLAY = {
     "speechain.module.prenet.conv1d": "speechain_amd.module.prenet.conv1d",
     "speechain.module.prenet.var_pred": "speechain_amd.module.prenet.var_pred",
     "speechain.module.prenet.embed": "speechain_amd.module.prenet.embed",
+    "speechain.module.prenet.spk_embed": "speechain_amd.module.prenet.spk_embed",
     "speechain.module.postnet.conv1d": "speechain_amd.module.postnet.conv1d",
     "speechain.module.encoder.tts": "speechain_amd.module.encoder.tts",
     "speechain.module.encoder.asr": "speechain_amd.module.encoder.asr",
@@ -62,10 +63,16 @@ def _ensure_package(name: str):
         return pkg
 
 
-def register(verbose: bool = False):
+# SpeeChain's own composite classes (they only string other modules together): with ``leaf_only=True`` they stay the reference's and
+# resolve their members -- by ``import_class`` string or by direct import -- to the overlaid leaves (tests/test_boundary_composites.py)
+COMPOSITES = ("speechain.module.encoder.asr", "speechain.module.encoder.tts", "speechain.module.decoder.ar_asr",
+              "speechain.module.decoder.nar_tts")
+
+
+def register(verbose: bool = False, leaf_only: bool = False):
     installed = []
     for target, source in OVERLAY.items():
-        if source is None:
+        if source is None or (leaf_only and target in COMPOSITES):
             continue
         mod = importlib.import_module(source)
         parent, _, child = target.rpartition(".")

@@ -768,6 +768,57 @@ def g13_ce_options():
     save("g13_ce_options", **out)
 
 
+# ---- G14 speaker embeddings (module/prenet/spk_embed.py:7-230; FastSpeech2Decoder.forward step 1, decoder/nar_tts.py:257-263) -----------
+SPK_CASES = dict(
+    # the VCTK recipes (recipes/tts/vctk/exp_cfg/16khz_ecapa_mfa_fastspeech2_mic2.yaml:228-230): pretrained vectors, concatenated
+    pre_cat=dict(d_model=48, spk_emb_dim_pretrained=24, spk_emb_comb="concat"),
+    # both sources added after their pre-projections (dims differ from d_model), decoder input combined by the same projection
+    both_add=dict(d_model=48, spk_emb_dim_lookup=16, spk_emb_dim_pretrained=24, spk_num=7, spk_emb_comb="add", dec_comb=True),
+    # lookup table only, concatenated, a projection of its own for the decoder input
+    look_cat=dict(d_model=48, spk_emb_dim_lookup=16, spk_num=7, spk_emb_comb="concat", dec_comb=True, encdec_same_proj=False),
+    # added without pre-projection (dims equal d_model)
+    pre_add_same=dict(d_model=48, spk_emb_dim_pretrained=48, spk_emb_comb="add"),
+)
+
+
+def g14_spk():
+    from speechain.module.prenet.spk_embed import SpeakerEmbedPrenet
+
+    g = torch.Generator().manual_seed(140)
+    B, L, T = 3, 9, 13
+    out = {}
+    for i, (tag, conf) in enumerate(SPK_CASES.items()):
+        m = SpeakerEmbedPrenet(**conf)
+        sd = seeded_state(m, 141 + i)
+        spk_ids = torch.tensor([3, 1, 6]) if m.use_lookup else None
+        spk_feat = torch.randn(B, conf["spk_emb_dim_pretrained"], generator=g) * 2.0 if m.use_pretrain else None
+        if tag == "both_add":
+            spk_feat = spk_feat.unsqueeze(1)  # (B, 1, D): the shape model/nar_tts.py:286 documents
+        enc = torch.randn(B, L, conf["d_model"], generator=g).requires_grad_()
+        dec = torch.randn(B, T, conf["d_model"], generator=g).requires_grad_() if conf.get("dec_comb") else None
+        look, pre = m(spk_ids=spk_ids, spk_feat=spk_feat)
+        enc_out, dec_out = m.combine_spk_feat(spk_feat=pre, spk_feat_lookup=look, enc_output=enc, dec_input=dec)
+        w1 = torch.randn(enc_out.shape, generator=g)
+        loss = (enc_out * w1).sum()
+        if dec_out is not None:
+            w2 = torch.randn(dec_out.shape, generator=g)
+            loss = loss + (dec_out * w2).sum()
+            out[f"{tag}.w2"], out[f"{tag}.dec"], out[f"{tag}.dec_out"] = w2, dec, dec_out
+        names = [n for n, _ in m.named_parameters()]
+        grads = torch.autograd.grad(loss, [p for _, p in m.named_parameters()] + [enc] + ([dec] if dec is not None else []))
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+        out.update({f"{tag}.grad.{n}": gr for n, gr in zip(names, grads)})
+        out[f"{tag}.grad_enc"] = grads[len(names)]
+        if dec is not None:
+            out[f"{tag}.grad_dec"] = grads[len(names) + 1]
+        out.update({f"{tag}.enc": enc, f"{tag}.enc_out": enc_out, f"{tag}.w1": w1})
+        if spk_ids is not None:
+            out[f"{tag}.spk_ids"], out[f"{tag}.look"] = spk_ids, look
+        if spk_feat is not None:
+            out[f"{tag}.spk_feat"], out[f"{tag}.pre"] = spk_feat, pre
+    save("g14_spk", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -784,3 +835,7 @@ if __name__ == "__main__":
     g8_featnorm()
     g9_prenet()
     g10_tts()
+    g11_decode()
+    g12_recover()
+    g13_ce_options()
+    g14_spk()

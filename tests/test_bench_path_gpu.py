@@ -188,8 +188,11 @@ def test_tts_timed_configuration_against_oracle(mode):
         if mode == "f32":
             Fn.set_compute_dtype(torch.float32)
             Fn.weights.invalidate()
-        tol_loss, tol_out, tol_grad, tol_curve = (5e-3, 2e-2, 6e-2, 3e-2) if mode == "bf16" else (1e-4, 1e-3, 5e-3, 2e-3)
-        wl.noam_warmup = 64  # lr = 384^-0.5 n 64^-1.5 = 1e-4 n: the weights move, the step stays stable
+        tol_loss, tol_out, tol_grad, tol_curve = (5e-3, 2e-2, 6e-2, 3e-2) if mode == "bf16" else (1e-4, 1e-3, 5e-3, 5e-3)
+        # lr = 384^-0.5 n 1024^-1.5 = 1.6e-6 n.  Chosen on the oracle alone: with this model's random initial weights the loss is 10.5 -> 9.6 ->
+        # 8.2 -> 7.0 -> 6.6 -> 6.6 over the six steps (monotone); warm-ups of 64 / 256 steps make the first Adam updates overshoot (8.7 -> 65 ->
+        # 10 -> 22 ...), a regime in which the two arithmetics still agree (3 % / 0.4 %) but that says little about either
+        wl.noam_warmup = 1024
         P = {k: v.detach().float().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and not k.endswith("posenc") and
                                                                 "mel_fbanks" not in k and "preemph" not in k and "_batch" not in k)
              for k, v in wl.model.state_dict().items()}
@@ -210,7 +213,7 @@ def test_tts_timed_configuration_against_oracle(mode):
             grads = {k: v.grad.clone() for k, v in P.items() if v.requires_grad}
             torch.nn.utils.clip_grad_norm_(leaves, 1.0)
             for g in oopt.param_groups:
-                g["lr"] = 384 ** -0.5 * min(n ** -0.5, n * 64 ** -1.5)
+                g["lr"] = 384 ** -0.5 * min(n ** -0.5, n * 1024 ** -1.5)
             oopt.step()
             return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, grads
 
@@ -245,7 +248,7 @@ def test_tts_timed_configuration_against_oracle(mode):
         # (posenc.alpha is ONE number, the sum of dy . posenc over every position: no averaging of the rounding noise over elements)
         bad = [(k, v) for k, v in worst if not v < (2 * tol_grad if k.endswith("posenc.alpha") else tol_grad)]
         assert not bad, bad[:10]
-        assert losses_o[0] - losses_o[-1] > 0.02 * losses_o[0], losses_o
+        assert losses_o[0] - losses_o[-1] > 0.1 * losses_o[0], losses_o
         for a, b in zip(losses_g, losses_o):
             assert abs(a - b) < tol_curve * abs(b), (losses_g, losses_o)
     finally:
