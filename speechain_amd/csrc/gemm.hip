@@ -763,6 +763,29 @@ typedef __attribute__((address_space(3))) void* sc_lptr_t;
 // KTAIL (PF 0 only): K is a multiple of 8 but not of 32 (the 5000-wide contraction of the vocabulary heads' data gradients).  The last
 // K tile is partial: lanes whose 16-byte source chunk lies beyond K read chunk 0 of that tile instead (valid memory), and the fragments
 // of the k-chunks beyond K are zeroed in registers before they reach the matrix cores.
+// -DSC_GEMM_TIMING (instrumented builds only, scripts/gemm_probe.py): every workgroup records s_memrealtime (100 MHz, chip-wide) and s_memtime
+// (shader cycles) at its phase boundaries, wave 0 lane 0; workgroup 0 also stamps four steady-state K tiles per wave.  Read back with
+// sc_gemm_debug_read (not part of the ABI).
+#ifdef SC_GEMM_TIMING
+__device__ long long sc_gemm_probe[1024 * 8 + 8 * 4 * 4];
+#define GT_WG(k)                                                                                                                \
+  do {                                                                                                                          \
+    const int id_ = blockIdx.y * gridDim.x + blockIdx.x;                                                                        \
+    if (lane == 0 && wid == 0 && id_ < 1024) {                                                                                  \
+      sc_gemm_probe[id_ * 8 + (k)] = __builtin_readcyclecounter();                                                              \
+      if ((k) == 0 || (k) == 3) sc_gemm_probe[id_ * 8 + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime();                     \
+    }                                                                                                                           \
+  } while (0)
+#define GT_IT(t, k)                                                                                                             \
+  do {                                                                                                                          \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t) >= 8 && (t) < 12)                                                \
+      sc_gemm_probe[1024 * 8 + (wid * 4 + ((t) - 8)) * 4 + (k)] = __builtin_readcyclecounter();                                 \
+  } while (0)
+#else
+#define GT_WG(k) do {} while (0)
+#define GT_IT(t, k) do {} while (0)
+#endif
+
 template <int WM, int WN, int MI, int PF, bool KTAIL = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf16_nt_dma_kernel(GemmArgs p) {
   static_assert(!KTAIL || PF == 0, "the K tail is implemented in the unpipelined loop only");
@@ -775,6 +798,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / WN, wc = wid % WN;
   const int h = lane >> 5, li = lane & 31;
+  GT_WG(0);
   int bx = blockIdx.x, by = blockIdx.y;
   {
     const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
@@ -884,10 +908,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   } while (0)
 #define SC_PUBLISH_STEADY(T)                                                                  \
   do {                                                                                        \
+    GT_IT(T, 0);                                                                              \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    GT_IT(T, 1);                                                                              \
     __builtin_amdgcn_s_barrier();                                                             \
+    GT_IT(T, 2);                                                                              \
     SC_DMA_ISSUE((T) + STAGES);                                                               \
+    GT_IT(T, 3);                                                                              \
   } while (0)
   if constexpr (PF == 0) {
   for (int t = 0; t < nk; ++t) {
@@ -952,6 +980,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
     bf16x8_t fa00[MI], fb00[2], fa01[MI], fb01[2], fa10[MI], fb10[2], fa11[MI], fb11[2];
     SC_WAIT_TILES(min(STAGES - 1, nk - 1));
     __builtin_amdgcn_s_barrier();
+    GT_WG(1);
     SC_FRAGS(0, 0, fa00, fb00);
     SC_FRAGS(0, 1, fa01, fb01);
     int t = 0;
@@ -994,11 +1023,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
 #undef SC_DMA_ISSUE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before they become epilogue staging
+  GT_WG(2);
 
   if constexpr (KTAIL)  // (data gradients: plain / bias / run-time general epilogue; keeps the number of instantiations down)
     epilogue_wave<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
   else
     epilogue_wave_fused<unsigned short, MI>(p, (float*)dsmem + wid * 32 * STG_LD, acc, zoffC, z, m0 + wr * MI * 32, n0 + wc * 64, lane);
+#ifdef SC_GEMM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores have left the wave)
+  GT_WG(3);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1469,6 +1503,11 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+#ifdef SC_GEMM_TIMING
+SC_API int sc_gemm_debug_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_gemm_probe), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif
 SC_API const char* sc_gemm_kernel_name(int id) {
   return (id >= 0 && id < (int)(sizeof(kGemmKernelNames) / sizeof(kGemmKernelNames[0]))) ? kGemmKernelNames[id] : "unknown";
 }

@@ -126,26 +126,26 @@ def test_transformer_small_hip_path_vs_oracle(mode):
         assert xe < (1e-5 if f32 else 2e-2), xe
         gm = model.cuda().train()
         out = gm(x, xlen, text.cuda(), text_len.cuda())
-        lt = dict(atol=2e-4, rtol=1e-3) if f32 else dict(atol=0.1, rtol=2e-2)
-        for k in ("ce", "ctc", "loss"):
-            assert torch.allclose(out[k].detach().float().cpu(), ref[k].detach(), **lt), (k, float(out[k]), float(ref[k]))
-        at = dict(atol=2e-3, rtol=1e-3) if f32 else dict(atol=0.25, rtol=6e-2)
-        assert torch.allclose(out["logits"].detach().float().cpu(), ref["logits"].detach(), **at)
-        assert torch.allclose(out["ctc_logits"].detach().float().cpu(), ref["ctc_logits"].detach(), **at)
+        relf = lambda a, b, floor=0.0: float((a.double() - b.double()).norm() / (b.double().norm() + floor + 1e-300))
+        for k in ("ce", "ctc", "loss"):  # f32: 1e-3 relative (north_star); bf16: 5e-3
+            a, b = float(out[k]), float(ref[k])
+            assert abs(a - b) < (1e-3 if f32 else 5e-3) * abs(b) + (2e-4 if f32 else 0.0), (k, a, b)
+        for k in ("logits", "ctc_logits"):  # relative Frobenius: f32 1e-4, bf16 2e-2 (12 + 6 layers of bf16 products, head size 36: unfused attention)
+            e = relf(out[k].detach().float().cpu(), ref[k].detach())
+            assert e < (1e-4 if f32 else 2e-2), (k, e)
         out["loss"].backward()
-        gt = dict(atol=2e-4, rtol=2e-3) if f32 else dict(atol=5e-2, rtol=0.1)
         pairs = [(gm.encoder.trfm_layers[0].multihead_att.q_layer.weight, "encoder.trfm_layers.0.multihead_att.q_layer.weight"),
                  (gm.encoder.trfm_layers[11].feed_forward.out_layer.weight, "encoder.trfm_layers.11.feed_forward.out_layer.weight"),
                  (gm.decoder.trfm_layers[5].encdec_att.k_layer.bias, "decoder.trfm_layers.5.encdec_att.k_layer.bias"),
                  (gm.decoder.trfm_layers[0].self_att_ln.weight, "decoder.trfm_layers.0.self_att_ln.weight"),
                  (gm.embed.embed.weight, "embed.weight"), (gm.ctc_layer.linear.weight, "ctc_layer.linear.weight")]
-        for prm, key in pairs:
-            g, r = prm.grad.detach().float().cpu(), P[key].grad
-            assert torch.allclose(g, r, **gt), (key, float((g - r).abs().max()), float(r.abs().max()))
+        total = sum(float(v.grad.double().pow(2).sum()) for v in P.values() if v.grad is not None) ** 0.5
+        for prm, key in pairs:  # relative Frobenius per parameter (floor: 3e-4 of the global gradient norm, for the key bias whose true gradient is zero)
+            e = relf(prm.grad.detach().float().cpu(), P[key].grad, floor=3.3e-4 * total)
+            assert e < (2e-3 if f32 else 4e-2), (key, e)
         for name, prm in gp.named_parameters():  # the prenet's gradients came back through 12 encoder layers
-            g, r = prm.grad.detach().float().cpu(), P["prenet." + name].grad
-            e = float((g - r).norm() / (r.norm() + 1e-30))
-            assert e < (5e-4 if f32 else 0.2), (name, e)
+            e = relf(prm.grad.detach().float().cpu(), P["prenet." + name].grad, floor=3.3e-4 * total)
+            assert e < (5e-4 if f32 else 6e-2), (name, e)
     finally:
         Fn.set_compute_dtype(None)
         Fn.weights.invalidate()

@@ -127,12 +127,12 @@ def test_fastspeech2_decoder_applies_the_speaker_vectors_first():
         mask = torch.ones(2, 1, 12, dtype=torch.bool).cuda()
         spk = torch.randn(2, 192, generator=g).cuda()
         with torch.no_grad():
-            a = with_spk(enc_text=enc, enc_text_mask=mask, spk_feat=spk)
+            a = with_spk(enc_text=enc, enc_text_mask=mask, spk_feat=spk, min_frame_num=0)
             look, pre = with_spk.spk_emb(spk_feat=spk)
             enc2, _ = with_spk.spk_emb.combine_spk_feat(spk_feat=pre, spk_feat_lookup=look, enc_output=enc)
-            b = plain(enc_text=enc2, enc_text_mask=mask)
+            b = plain(enc_text=enc2, enc_text_mask=mask, min_frame_num=0)
         assert torch.equal(a[2], b[2]) and torch.allclose(a[0].float(), b[0].float(), atol=1e-5) and torch.allclose(a[1].float(), b[1].float(), atol=1e-5)
-        assert not torch.allclose(a[0].float(), plain(enc_text=enc, enc_text_mask=mask)[0].float(), atol=1e-3)  # (the speaker vectors matter)
+        assert not torch.allclose(a[0].float(), plain(enc_text=enc, enc_text_mask=mask, min_frame_num=0)[0].float(), atol=1e-3)  # (the speaker vectors matter)
     finally:
         Fn.set_compute_dtype(None)
         Fn.weights.invalidate()

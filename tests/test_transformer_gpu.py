@@ -15,7 +15,13 @@ from speechain_amd import functional as Fn
 pytestmark = pytest.mark.gpu
 
 F32 = dict(atol=2e-4, rtol=1e-3)
-BF16 = dict(atol=6e-2, rtol=6e-2)
+# bf16 training mode: every comparison is a RELATIVE FROBENIUS error ||hip - ref|| / ||ref|| against the float32 fixture (an absolute
+# tolerance says nothing without the tensor's scale).  One bf16 rounding is 2^-9 = 2e-3 relative per element; a layer output carries a few
+# of them, a gradient a few more.  `floor` (added to the denominator) is for references that are zero in exact arithmetic.
+BF16 = dict(rel=1.5e-2)
+BF16_GRAD = dict(rel=3e-2)
+BF16_PROB = dict(rel=2e-2)
+MEASURED = []  # (what, relative error) of every bf16 comparison, printed at the end of the module with -s
 
 
 @pytest.fixture(params=[torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -32,8 +38,18 @@ def tol(mode):
 def close(a, b, t, what=""):
     a = a.detach().float().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
+    if "rel" in t:
+        e = float((a.double() - b.double()).norm() / (b.double().norm() + t.get("floor", 0.0) + 1e-300))
+        MEASURED.append((what, e))
+        assert e < t["rel"], (what, e, t)
+        return
     err = float((a - b).abs().max())
     assert torch.allclose(a, b, **t), (what, err)
+
+
+def teardown_module(module):
+    if MEASURED:
+        print("\nbf16 relative Frobenius errors:", ", ".join(f"{w} {e:.2e}" for w, e in MEASURED))
 
 
 def _w(x):
@@ -55,7 +71,7 @@ def test_posenc(golden, mode):
         pe = PositionalEncoding(posenc_type=typ, d_model=64, max_len=300)
         assert torch.equal(pe.posenc[0, [0, 1, 2, 17, 150, 299]], g[f"{typ}_rows"])
     pe = _load(PositionalEncoding(d_model=64, emb_scale=True, emb_layernorm=True, posenc_scale=True, max_len=300), sub(g, "full_sd."))
-    close(pe(g["x"].cuda()), g["full_out"], tol(mode) if mode == torch.float32 else dict(atol=0.15, rtol=3e-2), "posenc full")
+    close(pe(g["x"].cuda()), g["full_out"], tol(mode), "posenc full")
     pe2 = PositionalEncoding(d_model=64, max_len=300).cuda().eval()
     close(pe2(g["x"].cuda()), g["plain_out"], tol(mode), "posenc plain")
 
@@ -70,19 +86,19 @@ def test_mha(golden, mode):
         q, kv = g[f"{tag}.q"].cuda().requires_grad_(), g[f"{tag}.kv"].cuda().requires_grad_()
         y, p = m(kv, kv, q, g[f"{tag}.mask"].cuda())
         close(y, g[f"{tag}.out"], t, tag + " out")
-        close(p, g[f"{tag}.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0), tag + " probs")
+        close(p, g[f"{tag}.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else BF16_PROB, tag + " probs")
         gq, gkv, gw = torch.autograd.grad((y.float() * _w(y)).sum(), [q, kv, m.q_layer.weight])
         close(gq, g[f"{tag}.gq"], t, tag + " gq")
         close(gkv, g[f"{tag}.gkv"], t, tag + " gkv")
-        close(gw, g[f"{tag}.gw_q"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else dict(atol=0.3, rtol=6e-2), tag + " gw")
+        close(gw, g[f"{tag}.gw_q"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else BF16_GRAD, tag + " gw")
     # dh = 192, dense (B, T, T) causal & padding mask given explicitly
     m = _load(MultiHeadedAttention(num_heads=2, d_model=384, dropout=0.0), sub(g, "mha192.sd."))
     x = g["mha192.x"].cuda().requires_grad_()
     y, p = m(x, x, x, g["mha192.mask"].cuda())
     close(y, g["mha192.out"], t, "mha192 out")
-    close(p, g["mha192.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0), "mha192 probs")
+    close(p, g["mha192.probs"], dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else BF16_PROB, "mha192 probs")
     (gx,) = torch.autograd.grad((y.float() * _w(y)).sum(), [x])
-    close(gx, g["mha192.gx"], t if mode == torch.float32 else dict(atol=0.2, rtol=6e-2), "mha192 gx")
+    close(gx, g["mha192.gx"], t if mode == torch.float32 else BF16_GRAD, "mha192 gx")
     # same result when the causal structure is given as a flag + (B,1,T) padding mask (what the decoder stack does)
     pad = g["mha192.mask"][:, -1:, :].cuda()
     y2, p2 = m(x, x, x, pad, _causal=True)
@@ -102,7 +118,7 @@ def test_ffn(golden, mode, tag, act, typ):
     w = f.in_layer.weight if typ == "linear" else f.in_layer.conv_lyr.weight
     gx, gw = torch.autograd.grad((y.float() * _w(y)).sum(), [x, w])
     close(gx, g[f"{tag}.gx"], t, tag + " gx")
-    close(gw, g[f"{tag}.gw_in"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else dict(atol=0.6, rtol=6e-2), tag + " gw")
+    close(gw, g[f"{tag}.gw_in"], dict(atol=2e-3, rtol=1e-3) if mode == torch.float32 else BF16_GRAD, tag + " gw")
 
 
 def test_encoder_decoder_layers(golden, mode):
@@ -110,8 +126,8 @@ def test_encoder_decoder_layers(golden, mode):
     from speechain_amd.module.transformer.encoder import TransformerEncoderLayer
 
     g = golden("g4_layers")
-    t = tol(mode) if mode == torch.float32 else dict(atol=0.12, rtol=6e-2)
-    tg = dict(atol=2e-3, rtol=2e-3) if mode == torch.float32 else dict(atol=0.5, rtol=0.1)
+    t = tol(mode)
+    tg = dict(atol=2e-3, rtol=2e-3) if mode == torch.float32 else BF16_GRAD
     for tag, first in (("enc_pre", True), ("enc_post", False)):
         e = _load(TransformerEncoderLayer(d_model=64, num_heads=4, fdfwd_dim=128, att_dropout=0.0, fdfwd_dropout=0.0, res_dropout=0.0,
                                           fdfwd_activation="GELU", layernorm_first=first), sub(g, f"{tag}.sd."))
@@ -127,7 +143,7 @@ def test_encoder_decoder_layers(golden, mode):
     tgt, src = g["dec.tgt"].cuda().requires_grad_(), g["dec.src"].cuda().requires_grad_()
     y, sp, ep = d(tgt, src, g["dec.tmask"].cuda(), g["dec.smask"].cuda())
     close(y, g["dec.out"], t, "dec layer")
-    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=2e-2, rtol=0)
+    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else BF16_PROB
     close(sp, g["dec.self_probs"], pt, "dec self probs")
     close(ep, g["dec.encdec_probs"], pt, "dec encdec probs")
     gt, gs = torch.autograd.grad((y.float() * _w(y)).sum(), [tgt, src])
@@ -140,8 +156,8 @@ def test_stacks(golden, mode):
     from speechain_amd.module.transformer.encoder import TransformerEncoder
 
     g = golden("g5_stacks")
-    t = tol(mode) if mode == torch.float32 else dict(atol=0.15, rtol=6e-2)
-    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(atol=3e-2, rtol=0)
+    t = tol(mode) if mode == torch.float32 else dict(rel=2e-2)  # (two layers + final LayerNorm)
+    pt = dict(atol=1e-5, rtol=1e-4) if mode == torch.float32 else dict(rel=3e-2)
     enc = _load(TransformerEncoder(d_model=64, num_heads=4, num_layers=2, fdfwd_dim=128, posenc_dropout=0.0, att_dropout=0.0,
                                    fdfwd_dropout=0.0, res_dropout=0.0, fdfwd_activation="GELU", posenc_maxlen=200), sub(g, "enc.sd."))
     y, m, att, hid = enc(g["enc.x"].cuda(), g["enc.mask"].cuda())
@@ -198,8 +214,9 @@ def test_losses(golden, mode):
     from speechain_amd.criterion.ctc import CTCLoss
 
     g = golden("g6_losses")
-    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(atol=5e-2, rtol=2e-2)
-    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(atol=3e-3, rtol=5e-2)
+    # (bf16 mode feeds the criteria bf16-ROUNDED logits: the loss moves by the rounding of its input, not by the kernels' arithmetic)
+    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(rel=5e-3)
+    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(rel=2e-2)
     for tag, conf in (("ce0", dict()), ("ce02", dict(label_smoothing=0.2)), ("ce02n", dict(label_smoothing=0.2, length_normalized=True))):
         lg = g["ce_logits"].to(mode).cuda().requires_grad_()
         loss = CrossEntropy(**conf)(logits=lg, text=g["text"].cuda(), text_len=g["text_len"].cuda())
@@ -217,8 +234,9 @@ def test_cross_entropy_options(golden, mode, tmp_path):
     from speechain_amd.criterion.cross_entropy import CrossEntropy
 
     g = golden("g13_ce_options")
-    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(atol=5e-2, rtol=2e-2)
-    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(atol=3e-3, rtol=5e-2)
+    # (bf16 mode feeds the criteria bf16-ROUNDED logits: the loss moves by the rounding of its input, not by the kernels' arithmetic)
+    lt = dict(atol=1e-4, rtol=1e-4) if mode == torch.float32 else dict(rel=5e-3)
+    gt = dict(atol=1e-6, rtol=1e-3) if mode == torch.float32 else dict(rel=2e-2)
     vocab = tmp_path / "vocab"
     vocab.write_text("\n".join(f"tok{i}" for i in range(29)) + "\n")
     cases = dict(w=dict(label_smoothing=0.1, token_vocab=str(vocab), new_weights={"tok3": 2.5, "tok11": 0.25, "tok28": 0.0}),
@@ -297,18 +315,22 @@ def test_harness_step(golden, mode):
     sd["embed.embed.weight"] = sd.pop("embed.weight")
     _load(model, sd)
     out = model(g["feat"].cuda(), g["feat_len"].cuda(), g["text"].cuda(), g["text_len"].cuda())
-    t = tol(mode) if mode == torch.float32 else dict(atol=0.2, rtol=6e-2)
+    t = tol(mode) if mode == torch.float32 else dict(rel=2e-2)
     close(out["enc"], g["enc"], t, "enc")
     close(out["logits"], g["logits"], t, "logits")
     close(out["ctc_logits"], g["ctc_logits"], t, "ctc_logits")
-    lt = dict(atol=2e-4, rtol=2e-4) if mode == torch.float32 else dict(atol=0.1, rtol=2e-2)
+    lt = dict(atol=2e-4, rtol=2e-4) if mode == torch.float32 else dict(rel=5e-3)
     for k in ("ce", "ctc", "loss"):
         close(out[k], g[k], lt, k)
     out["loss"].backward()
-    gt = dict(atol=2e-4, rtol=2e-3) if mode == torch.float32 else dict(atol=5e-2, rtol=0.1)
+    gt = dict(atol=2e-4, rtol=2e-3) if mode == torch.float32 else dict(rel=4e-2)
     close(model.encoder.trfm_layers[0].multihead_att.q_layer.weight.grad, g["g_enc0_q"], gt, "g enc0 q")
     close(model.embed.embed.weight.grad, g["g_embed"], gt, "g embed")
-    close(model.decoder.trfm_layers[1].encdec_att.k_layer.bias.grad, g["g_dec1_encdec_kb"], gt, "g kb")
+    # (a key projection's bias has NO gradient in exact arithmetic -- softmax ignores a shift all keys share --: the fixture holds the
+    #  reference's rounding residue; measured against the scale of the query weight's gradient instead of its own)
+    kb_floor = float(g["g_enc0_q"].norm())
+    close(model.decoder.trfm_layers[1].encdec_att.k_layer.bias.grad, g["g_dec1_encdec_kb"],
+          gt if mode == torch.float32 else dict(rel=1e-3, floor=kb_floor), "g kb")
     close(model.ctc_layer.linear.weight.grad, g["g_ctc_w"], gt, "g ctc w")
 
 
