@@ -79,6 +79,12 @@ class FrontendWorkload:
         self.sa = SpecAugment(input_size=80, **SPECAUG).to(device)
         self.sa.train()
         self.wave, self.lens, self.lens_host = synth_batch(seed, device)
+        # The lengths are known on the host (a data loader made them): SpecAugment gets the frame counts as a CPU tensor and draws its
+        # indices on the host generator -- no device-to-host read, one pinned copy of the index tensors (module/augment/specaug.py).
+        # BENCH_DEVICE_DRAWS=1: device-resident lengths and draws on the device generator (three host round trips per step).
+        self.host_lens = os.environ.get("BENCH_DEVICE_DRAWS", "0") != "1"
+        self.sa.host_draws = self.host_lens
+        self.flen_host = self.fe.speech2linear.frame_count(self.lens_host)
         self.ev = []
 
     def step(self, timed: bool):
@@ -88,7 +94,7 @@ class FrontendWorkload:
         lib.timing = {"sc_frontend_logmel_fwd": self.ev} if timed else None
         feat, flen = self.fe(self.wave, self.lens)
         lib.timing = None
-        out, _ = self.sa(feat, flen)
+        out, _ = self.sa(feat, self.flen_host if self.host_lens else flen)
         return out
 
     def dominant_ms(self):

@@ -54,6 +54,7 @@ struct GemmArgs {
   int splitk;          // > 1: blockIdx.z is a K slice of ksplit_len, raw f32 partial tiles go to slab z of C
   int ksplit_len;
   float* colsum_part;  // split-K with a transposed A only: per-slice column sums of A over the contraction, (slices, M) f32, or null
+  int exp_flags;       // experiment switches (sc_gemm_experiment; 0 in production): 4 = static priority for the younger waves
 };
 
 template <typename T> struct Elem;
@@ -774,6 +775,12 @@ __device__ long long sc_gemm_probe[1024 * 8 + 8 * 4 * 4];
     if (lane == 0 && wid == 0 && id_ < 1024) {                                                                                  \
       sc_gemm_probe[id_ * 8 + (k)] = __builtin_readcyclecounter();                                                              \
       if ((k) == 0 || (k) == 3) sc_gemm_probe[id_ * 8 + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime();                     \
+      if ((k) == 0) {                                                                                                           \
+        unsigned hw_, xcc_;                                                                                                     \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                                     \
+        sc_gemm_probe[id_ * 8 + 6] = ((long long)xcc_ << 32) | hw_;                                                             \
+      }                                                                                                                         \
     }                                                                                                                           \
   } while (0)
 #define GT_IT(t, k)                                                                                                             \
@@ -786,24 +793,34 @@ __device__ long long sc_gemm_probe[1024 * 8 + 8 * 4 * 4];
 #define GT_IT(t, k) do {} while (0)
 #endif
 
-template <int WM, int WN, int MI, int PF, bool KTAIL = false>
+// HALFLOAD: only the first half of the waves (the older wave of every SIMD pair) issues the LDS-DMA instructions, twice as many each.  Two
+// waves share a SIMD; the one dispatched first wins the issue arbitration, the younger one reaches the barrier later by about the cost
+// of its DMA issue (scripts/gemm_probe.py): giving that work to the older half evens the two out.
+template <int WM, int WN, int MI, int PF, bool KTAIL = false, bool HALFLOAD = false, int SG = 4>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf16_nt_dma_kernel(GemmArgs p) {
   static_assert(!KTAIL || PF == 0, "the K tail is implemented in the unpipelined loop only");
   constexpr int NW = WM * WN, TM = WM * MI * 32, TN = WN * 64;
-  constexpr int STAGES = 4, STAGE_ELEMS = (TM + TN) * BK16;
-  constexpr int ACH = TM / 16 / NW, BCH = TN / 16 / NW;  // 1 KB chunks (16 rows) of A / B each wave stages per tile
+  constexpr int NL = HALFLOAD ? NW / 2 : NW;  // waves that stage operands
+  static_assert(!HALFLOAD || (NW == 8 && !KTAIL), "HALFLOAD is built for the 8-wave tiles");
+  constexpr int STAGES = SG, STAGE_ELEMS = (TM + TN) * BK16;  // (SG: ring depth, a power of two; 4 everywhere but in the depth experiment)
+  static_assert((SG & (SG - 1)) == 0 && SG >= 4 && SG <= 8, "ring depth");
+  constexpr int ACH = TM / 16 / NL, BCH = TN / 16 / NL;  // 1 KB chunks (16 rows) of A / B each staging wave moves per tile
   extern __shared__ __attribute__((aligned(1024))) unsigned short dsmem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / WN, wc = wid % WN;
   const int h = lane >> 5, li = lane & 31;
+  const bool loader = !HALFLOAD || wid < NL;
+  if (p.exp_flags & 4) {  // (experiment: static priority for the younger half of the waves)
+    if (wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   GT_WG(0);
   int bx = blockIdx.x, by = blockIdx.y;
   {
     const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
     if (nwg >= 16) {
-      const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+      const int xcd = ((orig & 7) + ((p.exp_flags >> 3) & 7)) & 7, q = nwg >> 3, r = nwg & 7;  // (experiment bits 3..5: rotate the labels)
       const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
       by = id / gx;
       bx = id - by * gx;
@@ -822,12 +839,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   const unsigned short* bsrc[BCH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
-    const int row = (wid + NW * i) * 16 + (lane >> 2);
+    const int row = ((wid % NL) + NL * i) * 16 + (lane >> 2);
     asrc[i] = A + (long long)min(m0 + row, p.M - 1) * p.lda + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
-    const int row = (wid + NW * i) * 16 + (lane >> 2);
+    const int row = ((wid % NL) + NL * i) * 16 + (lane >> 2);
     bsrc[i] = B + (long long)min(n0 + row, p.N - 1) * p.ldb + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
   }
 
@@ -846,19 +863,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
   const int tail_adj = (KTAIL && (((lane & 3) ^ ((lane >> 4) & 3)) * 8 >= ktail)) ? ((lane & 3) ^ ((lane >> 4) & 3)) * 8 : 0;
 #define SC_DMA_ISSUE(T)                                                                                                \
   do {                                                                                                                 \
-    unsigned short* st_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                                                        \
-    const int koff_ = (T) * BK16 - ((KTAIL && (T) == nk - 1) ? tail_adj : 0);                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < ACH; ++i_)                                                                 \
-      __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + koff_), (sc_lptr_t)(st_ + (wid + NW * i_) * 512), 16, 0, 0); \
-    _Pragma("unroll") for (int i_ = 0; i_ < BCH; ++i_)                                                                 \
-      __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + koff_),                                                  \
-                                       (sc_lptr_t)(st_ + TM * BK16 + (wid + NW * i_) * 512), 16, 0, 0);                \
+    if (loader) {                                                                                                      \
+      unsigned short* st_ = dsmem + ((T) % STAGES) * STAGE_ELEMS;                                                      \
+      const int koff_ = (T) * BK16 - ((KTAIL && (T) == nk - 1) ? tail_adj : 0);                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < ACH; ++i_)                                                               \
+        __builtin_amdgcn_global_load_lds((sc_gptr_t)(asrc[i_] + koff_), (sc_lptr_t)(st_ + ((wid % NL) + NL * i_) * 512), 16, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < BCH; ++i_)                                                               \
+        __builtin_amdgcn_global_load_lds((sc_gptr_t)(bsrc[i_] + koff_),                                                \
+                                         (sc_lptr_t)(st_ + TM * BK16 + ((wid % NL) + NL * i_) * 512), 16, 0, 0);       \
+    }                                                                                                                  \
   } while (0)
 
-  if (nk > 0) SC_DMA_ISSUE(0);
-  if (nk > 1) SC_DMA_ISSUE(1);
-  if (nk > 2) SC_DMA_ISSUE(2);
-  if (PF != 0 && nk > 3) SC_DMA_ISSUE(3);
+#pragma unroll
+  for (int i = 0; i < (PF != 0 ? STAGES : STAGES - 1); ++i)
+    if (nk > i) SC_DMA_ISSUE(i);
 
   // fragment read offsets (elements) inside an operand tile: row = base + li, 16-byte chunk (2*ks + h) swizzled
   int aoff[MI][2], boff[2][2];
@@ -880,7 +898,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
 #define SC_WAIT_TILES(AHEAD)                                                                  \
   do {                                                                                        \
     const int ah_ = (AHEAD);                                                                  \
-    if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");              \
+    if (!loader) break; /* (a wave that stages nothing has nothing in flight) */              \
+    if (STAGES > 4 && ah_ >= 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * LPT) : "memory"); \
+    else if (STAGES > 4 && ah_ == 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPT) : "memory"); \
+    else if (STAGES > 4 && ah_ == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPT) : "memory"); \
+    else if (STAGES > 4 && ah_ == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory"); \
+    else if (ah_ >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");         \
     else if (ah_ == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");         \
     else if (ah_ == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");             \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
@@ -909,7 +932,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
 #define SC_PUBLISH_STEADY(T)                                                                  \
   do {                                                                                        \
     GT_IT(T, 0);                                                                              \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");                 \
+    if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
     GT_IT(T, 1);                                                                              \
     __builtin_amdgcn_s_barrier();                                                             \
@@ -922,7 +945,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_bf1
     // tile t must have landed: every wave waits for its own DMA (counted: later tiles stay in flight), then the barrier
     // makes all waves' pieces visible and proves everyone is done reading the stage that tile t+3 overwrites.
     const int ahead = min(2, nk - 1 - t);
-    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    if (!loader) {}
+    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1289,17 +1313,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_dma_splitk_kernel(GemmArg
   }
 }
 
-template <int WM, int WN, int MI, int PF, bool KTAIL = false>
-int launch_dma_pf(const GemmArgs& a, int nbatch, hipStream_t stream) {
+static int g_gemm_exp = 0;  // experiment switches, see sc_gemm_experiment
+
+template <int WM, int WN, int MI, int PF, bool KTAIL = false, bool HALFLOAD = false, int SG = 4>
+int launch_dma_pf(const GemmArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int TM = WM * MI * 32, TN = WN * 64;
-  constexpr size_t smem_ring = (size_t)4 * (TM + TN) * BK16 * sizeof(unsigned short), smem_stg = (size_t)WM * WN * 32 * STG_LD * sizeof(float);
-  constexpr size_t smem = smem_ring > smem_stg ? smem_ring : smem_stg;  // (the operand stages double as the epilogue staging)
-  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF, KTAIL>;
+  constexpr size_t smem_ring = (size_t)SG * (TM + TN) * BK16 * sizeof(unsigned short), smem_stg = (size_t)WM * WN * 32 * STG_LD * sizeof(float);
+  size_t smem = smem_ring > smem_stg ? smem_ring : smem_stg;  // (the operand stages double as the epilogue staging)
+  GemmArgs a = a_in;
+  a.exp_flags = g_gemm_exp;
+  dim3 grid(sc_cdiv(a.N, TN), sc_cdiv(a.M, TM), nbatch);
+  // (experiment 1: a launch with at most one workgroup per CU asks for more than half the LDS, so that no two of them can share a CU)
+  if ((g_gemm_exp & 1) && (long long)grid.x * grid.y * grid.z <= 256 && smem <= 80 * 1024) smem = 96 * 1024;
+  auto kernel = gemm_bf16_nt_dma_kernel<WM, WN, MI, PF, KTAIL, HALFLOAD, SG>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return sc_set_error(SC_ERR_LAUNCH, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   }
-  dim3 grid(sc_cdiv(a.N, TN), sc_cdiv(a.M, TM), nbatch);
   hipLaunchKernelGGL(kernel, grid, dim3(64 * WM * WN), smem, stream, a);
   SC_LAUNCH_CHECK("gemm_bf16_nt_dma_kernel");
   return SC_OK;
@@ -1503,6 +1533,10 @@ static const char* const kGemmKernelNames[] = {
     "gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+// Experiment switches for A/B runs inside ONE process (scripts/ab_gemm_exp.py); not part of the ABI.  bit 0: launches of at most 256
+// workgroups take a CU each; bit 1: the 8-wave 128 x 128 kernel lets its older four waves issue every LDS-DMA; bit 2: static priority 1 for
+// the younger four waves.
+SC_API void sc_gemm_experiment(int flags) { g_gemm_exp = flags; }
 #ifdef SC_GEMM_TIMING
 SC_API int sc_gemm_debug_read(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_gemm_probe), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : 1;
@@ -1585,6 +1619,8 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
         g_last_gemm_kernel = 15;
         if (w8 == 1) return launch_dma_pf<4, 2, 1, 0>(a, nb, stream);
         if (w8 == 2) return launch_dma_pf<4, 2, 1, 1>(a, nb, stream);
+        if (g_gemm_exp & 64) return launch_dma_pf<4, 2, 1, 2, false, false, 8>(a, nb, stream);  // (experiment 64: eight stages in the ring)
+        if (g_gemm_exp & 2) return launch_dma_pf<4, 2, 1, 2, false, true>(a, nb, stream);  // (experiment 2: the older half stages)
         return launch_dma_pf<4, 2, 1, 2>(a, nb, stream);
       }
       g_last_gemm_kernel = 1;

@@ -8,6 +8,12 @@ bit-identical to the reference's wherever it runs.  Warp + mask + fill are then 
 
 Difference kept on purpose: the input ``feat`` is not modified (the reference writes the warped rows back into its
 argument, :123-124, before ``masked_fill`` makes the returned copy).
+
+Host round trips.  The reference's draw order forces three device-to-host reads per call when everything lives on the GPU: the shortest
+length (:87) and the largest drawn mask length of each kind (:155, :188: the next ``randint``'s bound).  A caller that has the lengths on
+the host -- every data loader does -- may pass ``feat_len`` as a CPU tensor (it is returned as it came) and set ``host_draws = True`` on the
+module: all six draws then use the default CPU generator (the stream the reference itself uses when its features are CPU tensors: the
+golden fixtures), nothing is read back from the device, and the four index tensors travel in ONE pinned host-to-device copy.
 """
 from typing import Dict, List, Optional, Union
 
@@ -47,6 +53,7 @@ class SpecAugment(Module):
             raise ValueError
         self.time_mask_width, self.time_mask_num = time_mask_width, time_mask_num
         self.feat_norm = feat_norm
+        self.host_draws = False  # (see the module docstring; an attribute, not a keyword: the constructor stays the reference's)
 
     def draw(self, feat_len: torch.Tensor, batch_size: int, feat_dim: int, device) -> Dict:
         """The random integers of one call, drawn exactly as specaug.py:87-191 does (host logic, no kernel)."""
@@ -83,8 +90,17 @@ class SpecAugment(Module):
         x = feat.float().contiguous()
         B, T, Fd = x.shape
         dev = x.device
+        idx = [draws["freq_len"], draws["freq_pos"], draws["time_len"], draws["time_pos"]]
+        host = [t for t in idx if t is not None and not t.is_cuda]
+        if len(host) > 1:  # host-side draws: one pinned staging buffer, one copy, four views
+            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in host]).pin_memory().to(dev, non_blocking=True)
+            off = 0
+            for i, t in enumerate(idx):
+                if t is not None and not t.is_cuda:
+                    idx[i] = flat[off: off + t.numel()].view(t.shape)
+                    off += t.numel()
         i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
-        fl, fp, tl, tp = i64(draws["freq_len"]), i64(draws["freq_pos"]), i64(draws["time_len"]), i64(draws["time_pos"])
+        fl, fp, tl, tp = (i64(t) for t in idx)
         nf = 0 if fl is None else fl.size(1)
         nt = 0 if tl is None else tl.size(1)
         c = -1 if draws["warp_center"] is None else int(draws["warp_center"])
@@ -105,7 +121,7 @@ class SpecAugment(Module):
 
     def forward(self, feat: torch.Tensor, feat_len: torch.Tensor):
         require_gpu(feat, "SpecAugment")
-        draws = self.draw(feat_len, feat.size(0), feat.size(-1), feat.device)
+        draws = self.draw(feat_len, feat.size(0), feat.size(-1), torch.device("cpu") if self.host_draws else feat.device)
         return self.apply(feat, draws), feat_len
 
     def extra_repr(self) -> str:

@@ -158,6 +158,12 @@ class Speech2LinearSpec(Module):
         lo, hi = x.min(dim=1, keepdim=True)[0], x.max(dim=1, keepdim=True)[0]
         return (x - lo) / (hi - lo) * 2 - 1, None
 
+    def frame_count(self, speech_len: torch.Tensor) -> torch.Tensor:
+        """Number of frames of utterances of `speech_len` samples, on the tensor's own device (speech2linear.py:201-212) -- for callers
+        that keep the lengths on the host as well (the kernel writes the same numbers to the device-side ``feat_len`` it returns)."""
+        n = speech_len + (2 * (self.n_fft // 2) if self.stft_config["center"] else 0)
+        return torch.div(n - self.n_fft, self.hop_length, rounding_mode="floor") + 1
+
     def forward(self, speech: torch.Tensor, speech_len: torch.Tensor):
         speech, preemph = self._prepare(speech, speech_len)
         _, lin, energy, feat_len = run_frontend(
