@@ -339,6 +339,24 @@ int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
  * each, and dQ is summed through (B H, Tq, 64) floats in launch order (dq_workspace may be NULL otherwise). */
 long long sc_attention_bwd_workspace(int B, int H, int Tq, int Tk);
 
+/* Fused attention for any head size that is a multiple of 8 up to 256 (csrc/attention_dh.hip): the reference's attention is head-size
+ * agnostic (speechain/module/transformer/attention.py:53-65,88-106,131); FastSpeech2 runs 2 heads of 192
+ * (recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:40-43).  Same semantics, dropout indices and saved logsumexp as
+ * sc_attention_fwd / sc_attention_bwd with `head_dim` explicit (head h of a row starts at element h * head_dim); masks are (B, 1, Tk) key
+ * masks (mask_b = batch stride in bytes, null = none) and / or the causal flag.  The backward pass is three launches -- rowsum(dO * O) into
+ * `workspace` (sc_attention_dh_bwd_workspace bytes), dK / dV by key blocks, dQ by query blocks -- with no atomics: deterministic. */
+int sc_attention_dh_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Tq, int Tk, int head_dim,
+                        long long q_b, long long ldq, long long kv_b, long long ldk, long long o_b, long long ldo,
+                        const unsigned char* mask, long long mask_b, int causal, float scale, float drop_p,
+                        const unsigned long long* seed, unsigned long long offset, hipStream_t stream);
+long long sc_attention_dh_bwd_workspace(int B, int H, int Tq);
+int sc_attention_dh_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, void* dQ, void* dK,
+                        void* dV, int B, int H, int Tq, int Tk, int head_dim, long long q_b, long long ldq, long long kv_b,
+                        long long ldk, long long o_b, long long ldo, long long dq_b, long long lddq, long long dkv_b, long long lddk,
+                        const unsigned char* mask, long long mask_b, int causal, float scale, float drop_p,
+                        const unsigned long long* seed, unsigned long long offset, float* workspace, long long ws_bytes,
+                        hipStream_t stream);
+
 /* ---- cached-key/value decoding (csrc/decode.hip): the inference callers of SURVEY.md row f3 --------------------------------
  * Replaces, inside speechain/infer_func/beam_search.py:325-333 + :518-521, the re-run of the whole decoder on the whole prefix at
  * every step and the re-ordering of per-row tensors by beam_idx.

@@ -1284,6 +1284,7 @@ class _AttnCore(torch.autograd.Function):
 
 
 _want_probs = True
+_ATTN_ANY_DH = _os.environ.get("SC_ATTN_ANY_DH", "1") == "1"  # (A/B knob: 0 = head sizes other than 64 take the unfused GEMM + softmax path)
 
 
 def set_attention_probs(flag: bool):
@@ -1313,9 +1314,14 @@ class _AttnFused(torch.autograd.Function):
             mb, mq = m8.stride(0), (m8.stride(1) if m8.size(1) > 1 else 0)
         ld = _up(Tk, 8)
         seed, off = DropoutState.next(B * H * Tq * ld, dev) if drop_p > 0 else (0, 0)
-        lib.call("sc_attention_fwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(lse), B, H, Tq, Tk,
-                 q_buf.stride(0), q_buf.stride(1), kv_buf.stride(0), kv_buf.stride(1), out.stride(0), out.stride(1), _p(m8), mb, mq,
-                 1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
+        if d // H != 64:  # any other head size (a multiple of 8 up to 256; key masks / causal flag only): csrc/attention_dh.hip
+            lib.call("sc_attention_dh_fwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(lse), B, H, Tq, Tk, d // H,
+                     q_buf.stride(0), q_buf.stride(1), kv_buf.stride(0), kv_buf.stride(1), out.stride(0), out.stride(1), _p(m8), mb,
+                     1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
+        else:
+            lib.call("sc_attention_fwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(lse), B, H, Tq, Tk,
+                     q_buf.stride(0), q_buf.stride(1), kv_buf.stride(0), kv_buf.stride(1), out.stride(0), out.stride(1), _p(m8), mb, mq,
+                     1 if causal else 0, float(scale), float(drop_p), seed, off, stream())
         ctx.save_for_backward(q_buf, kv_buf, m8, lse, out)
         ctx.meta = (same, iq, ik, iv, H, d, causal, scale, drop_p, seed, off, ld, mb, mq)
         return out
@@ -1334,6 +1340,16 @@ class _AttnFused(torch.autograd.Function):
         sqb, skb = q_buf.stride(0), kv_buf.stride(0)
         zs = (H * Tq * ld, Tq * ld)
         dout = dout.contiguous()
+        if mq == 0 and dh != 64:  # (head sizes other than 64: rowsum(dO * O), then dK / dV by key blocks and dQ by query blocks)
+            dq_buf = torch.empty_like(q_buf)
+            dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
+            ws_bytes = lib.value("sc_attention_dh_bwd_workspace", B, H, Tq)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+            lib.call("sc_attention_dh_bwd", _p(q_buf, iq * d), _p(kv_buf, ik * d), _p(kv_buf, iv * d), _p(out), _p(dout), _p(lse),
+                     _p(dq_buf, iq * d), _p(dkv_buf, ik * d), _p(dkv_buf, iv * d), B, H, Tq, Tk, dh, sqb, ldq, skb, ldk, out.stride(0),
+                     out.stride(1), dq_buf.stride(0), dq_buf.stride(1), dkv_buf.stride(0), dkv_buf.stride(1), _p(m8), mb,
+                     1 if causal else 0, float(scale), float(drop_p), seed, off, _p(ws), ws_bytes, stream())
+            return dq_buf, (None if same else dkv_buf), None, None, None, None, None, None, None, None, None, None
         if mq == 0:  # fused backward: probabilities are recomputed on chip from Q, K and the saved logsumexp
             dq_buf = torch.empty_like(q_buf)
             dkv_buf = dq_buf if same else torch.empty_like(kv_buf)
@@ -1376,7 +1392,9 @@ def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, 
     # (any number of keys: the streaming forward tiles them, the backward sweeps them in blocks of 256.  A query-dependent mask -- only
     #  Conformer-style subclasses pass one -- takes the forward kernel that holds a head's keys in LDS: at most 256)
     dense_mask = mask is not None and mask.dim() == 3 and mask.size(1) > 1
-    if (not _want_probs and q_buf.dtype == torch.bfloat16 and d_model // num_heads == 64 and (Tk <= 256 or not dense_mask)
+    dh = d_model // num_heads
+    fused_ok = (dh == 64 and (Tk <= 256 or not dense_mask)) or (_ATTN_ANY_DH and dh != 64 and dh % 8 == 0 and dh <= 256 and not dense_mask)
+    if (not _want_probs and q_buf.dtype == torch.bfloat16 and fused_ok
             and q_buf.stride(1) % 8 == 0 and (same or kv_buf.stride(1) % 8 == 0)):
         out = _AttnFused.apply(q_buf, None if same else kv_buf, same, iq, ik, iv, num_heads, d_model, mask, bool(causal), float(scale),
                                float(drop_p))
