@@ -339,6 +339,16 @@ int sc_attention_bwd(const void* Q, const void* K, const void* V, const void* O,
  * each, and dQ is summed through (B H, Tq, 64) floats in launch order (dq_workspace may be NULL otherwise). */
 long long sc_attention_bwd_workspace(int B, int H, int Tq, int Tk);
 
+/* Linear layers of ONE decoding step (csrc/decode_gemm.hip): y (M, N) = act(LayerNorm(x) w^T + bias) + residual in bf16 for the few hundred
+ * hypothesis rows of a beam-search step (the reference re-runs its whole decoder per step: speechain/infer_func/beam_search.py:325-333; the
+ * layers are those of module/transformer/decoder.py:90-148).  w is an nn.Linear weight (N, K) row-major; bias (N) f32 or null; ln_gamma /
+ * ln_beta (K) f32 or both null -- with them, nn.LayerNorm(K, eps) of every row of x is folded in front of the product (needs K <= 512: the
+ * whole row on chip); act: 0 none, 1 ReLU, 2 GELU (applied before the residual is added); residual (M, N) bf16 or null.  K a multiple of 32,
+ * 16-byte aligned rows.  A 64 x 64 output tile's whole contraction is requested at once instead of in 32-deep pipelined tiles. */
+int sc_decode_linear(const void* x, long long ldx, int M, int K, const void* w, long long ldw, int N, const float* bias,
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, int act, const void* residual, long long ldr, void* y,
+                     long long ldy, hipStream_t stream);
+
 /* Fused attention for any head size that is a multiple of 8 up to 256 (csrc/attention_dh.hip): the reference's attention is head-size
  * agnostic (speechain/module/transformer/attention.py:53-65,88-106,131); FastSpeech2 runs 2 heads of 192
  * (recipes/tts/ljspeech/exp_cfg/22.05khz_mfa_fastspeech2.yaml:40-43).  Same semantics, dropout indices and saved logsumexp as

@@ -1927,6 +1927,48 @@ def beam_table_update(table_in: Optional[torch.Tensor], table_out: torch.Tensor,
     lib.call("sc_beam_table_update", _p(table_in), _p(table_out), _p(beam_idx), N, Tmax, int(pos), stream())
 
 
+_DECODE_LINEAR = _os.environ.get("SC_DECODE_LINEAR", "1") == "1"  # (A/B knob: 0 = LayerNorm launch + the general GEMM kernel)
+
+
+def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], ln: Optional[torch.nn.LayerNorm] = None,
+                  activation: Optional[str] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inference-only linear layer for the rows of one decoding step: ``act(LayerNorm(x) W^T + b) + residual`` in ONE launch
+    (csrc/decode_gemm.hip: the whole contraction of a 64 x 64 tile requested at once; the LayerNorm folded in when the row fits on chip).
+    Falls back to ``layer_norm`` + ``linear`` / ``linear_act`` where the kernel does not apply (f32 parity mode, odd sizes)."""
+    x2 = x.reshape(-1, x.size(-1))
+    K = x2.size(1)
+    n_out = sum(w.size(0) for w in ws)
+    # Measured per product at 512 rows (scripts/bench_decode_linear.py, launches back to back): the narrow products (N = 512: out 3.7 vs
+    # 6.5 us, LayerNorm + q 6.5 vs 8.7) and the long contraction (ffn-out, K = 2048: 7.3 vs 13.4) win; the wide ones (q|k|v 12.5 vs 9.0,
+    # ffn-in 14.3 vs 10.2, the 5000-wide head 39 vs 16) lose -- every column tile re-stages and re-normalises its rows -- and stay on the
+    # LayerNorm launch + the general kernel.
+    wide = n_out > 1024 and K <= 512
+    ok = (_DECODE_LINEAR and not wide and x2.dtype == torch.bfloat16 and x2.is_cuda and K % 32 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+          and (ln is None or K <= 512) and (activation is None or activation in ("ReLU", "GELU")) and not torch.is_grad_enabled())
+    if not ok:
+        if ln is not None:
+            x = layer_norm(x, ln.weight, ln.bias, ln.eps)
+        if activation is not None:
+            assert len(ws) == 1
+            y = linear_act(x, ws[0], bs[0], activation)
+            return y if residual is None else y + residual
+        return linear(x, ws, bs, residual=residual)
+    W = weights.fused(ws, x2.dtype)
+    b = weights.vector(bs)
+    M, N = x2.size(0), W.size(0)
+    y = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
+    res2 = None
+    if residual is not None:
+        res2 = residual.reshape(M, N)
+        if res2.stride(1) != 1:
+            res2 = res2.contiguous()
+    act = 0 if activation is None else ACT[activation]
+    lib.call("sc_decode_linear", _p(x2), x2.stride(0), M, K, _p(W), W.stride(0), N, _p(b), _p(ln.weight.detach()) if ln is not None else None,
+             _p(ln.bias.detach()) if ln is not None else None, float(ln.eps) if ln is not None else 0.0, act, _p(res2),
+             res2.stride(0) if res2 is not None else 0, _p(y), N, stream())
+    return y.reshape(*x.shape[:-1], N)
+
+
 def attention_decode(qkv: torch.Tensor, cache: torch.Tensor, table: torch.Tensor, pos: int, num_heads: int, scale: float) -> torch.Tensor:
     """One step of causal self-attention over cached keys / values: qkv (N, 3 d) this step's projections, cache (N, Tmax, 2 d) (slot
     (n, pos) is written), table (N, Tmax) int32 ancestry.  Returns the (N, d) context.  Heads of 64 only."""

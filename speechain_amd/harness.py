@@ -119,7 +119,7 @@ class _HarnessDecoder:
         m = self.m
         with torch.no_grad():
             emb = m.embed(tokens.unsqueeze(1)).squeeze(1)
-            return m.postnet(m.decoder.forward_step(emb, cache, beam_idx))
+            return m.decoder.token_head_step(emb, cache, beam_idx, m.postnet.linear)
 
 
 class TTSFastSpeech2(torch.nn.Module):

@@ -40,4 +40,6 @@ class ARASRDecoder(Module):
         """tokens (N,) int64: the newest token of every hypothesis row; returns the (N, vocab) logits of the next one."""
         with torch.no_grad():
             emb = self.embedding(tokens.unsqueeze(1)).squeeze(1)
+            if hasattr(self.decoder, "token_head_step"):
+                return self.decoder.token_head_step(emb, cache, beam_idx, self.postnet.linear)
             return self.postnet(self.decoder.forward_step(emb, cache, beam_idx))

@@ -71,26 +71,27 @@ class TransformerDecoderLayer(Module):
         with the earlier positions' keys / values taken from ``self_cache`` (N, Tmax, 2 d) through the ancestry ``table`` and the
         encoder side from ``cross_kv`` (B, Tk, 2 d), shared by the ``beam`` adjacent rows of a sentence."""
         first = self.layernorm_first
-        sa, ea = self.self_att, self.encdec_att
+        sa, ea, ff = self.self_att, self.encdec_att, self.feed_forward
         d, H = sa.d_model, sa.num_heads
-        xn = _ln(self.self_att_ln, x) if first else x
-        qkv = Fn.linear(xn, [sa.q_layer.weight, sa.k_layer.weight, sa.v_layer.weight], [sa.q_layer.bias, sa.k_layer.bias, sa.v_layer.bias])
+        # every product of the step is one launch of csrc/decode_gemm.hip (Fn.decode_linear): a pre-LN layer's LayerNorm is folded in front of the
+        # product that consumes it, the residual connection behind the one that closes a sublayer
+        pre = lambda ln: ln if first else None
+        post = lambda ln, v: v if first else _ln(ln, v)
+        qkv = Fn.decode_linear(x, [sa.q_layer.weight, sa.k_layer.weight, sa.v_layer.weight], [sa.q_layer.bias, sa.k_layer.bias, sa.v_layer.bias],
+                               ln=pre(self.self_att_ln))
         ctx = Fn.attention_decode(qkv, self_cache, table, pos, H, sa.scale)
-        x = Fn.linear(ctx, [sa.output_layer.weight], [sa.output_layer.bias], residual=x)
-        if not first:
-            x = _ln(self.self_att_ln, x)
-        xn = _ln(self.encdec_att_ln, x) if first else x
-        q = Fn.linear(xn, [ea.q_layer.weight], [ea.q_layer.bias])
+        x = post(self.self_att_ln, Fn.decode_linear(ctx, [sa.output_layer.weight], [sa.output_layer.bias], residual=x))
+        q = Fn.decode_linear(x, [ea.q_layer.weight], [ea.q_layer.bias], ln=pre(self.encdec_att_ln))
         B = cross_kv.size(0)
         ctx, _ = Fn.attention_core(q.view(B, beam, d), cross_kv, 0, 0, 1, H, d, src_mask, False, ea.scale, 0.0)
-        x = Fn.linear(ctx.reshape(B * beam, d), [ea.output_layer.weight], [ea.output_layer.bias], residual=x)
-        if not first:
-            x = _ln(self.encdec_att_ln, x)
-        xn = _ln(self.fdfwd_ln, x) if first else x
-        x = self.feed_forward(xn, _residual=x, _res_drop=0.0)
-        if not first:
-            x = _ln(self.fdfwd_ln, x)
-        return x
+        x = post(self.encdec_att_ln, Fn.decode_linear(ctx.reshape(B * beam, d), [ea.output_layer.weight], [ea.output_layer.bias], residual=x))
+        if isinstance(ff.in_layer, nn.Linear):
+            hmid = Fn.decode_linear(x, [ff.in_layer.weight], [ff.in_layer.bias], ln=pre(self.fdfwd_ln), activation=ff.activation_name)
+            x = Fn.decode_linear(hmid, [ff.out_layer.weight], [ff.out_layer.bias], residual=x)
+        else:  # (convolutional feed-forward: no single-position form; as before)
+            xn = _ln(self.fdfwd_ln, x) if first else x
+            x = ff(xn, _residual=x, _res_drop=0.0)
+        return post(self.fdfwd_ln, x)
 
 
 class DecodeCache:
@@ -176,10 +177,11 @@ class TransformerDecoder(Module):
         self_kv = [torch.zeros(N, max_len, 2 * d, dtype=src.dtype, device=src.device) for _ in self.trfm_layers]
         return DecodeCache(self_kv, cross, src_mask.clone(), beam, max_len, src.device)
 
-    def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None) -> torch.Tensor:
+    def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None, _skip_final_ln: bool = False) -> torch.Tensor:
         """tgt (N, d): the embedded token every hypothesis row feeds at position ``cache.pos``; ``beam_idx`` (N,) int64: the row each
         hypothesis continues (the selection of the previous step; None = unchanged order).  Returns the (N, d) decoder output of that
-        position -- what ``forward`` gives at the last position of the prefix."""
+        position -- what ``forward`` gives at the last position of the prefix.  ``_skip_final_ln``: the caller folds the stack's final
+        LayerNorm (``self.layernorm``, pre-LN stacks) into the product that follows (``token_head_step``)."""
         pos = cache.pos
         if pos >= cache.max_len:
             raise RuntimeError(f"speechain_amd: the decoding cache holds {cache.max_len} positions")
@@ -189,7 +191,13 @@ class TransformerDecoder(Module):
             x = self.posenc.forward_step(tgt, pos)
             for layer, kv, ckv in zip(self.trfm_layers, cache.self_kv, cache.cross_kv):
                 x = layer.forward_step(x, kv, t_out, pos, ckv, cache.src_mask, cache.beam)
-            if self.layernorm_first:
+            if self.layernorm_first and not _skip_final_ln:
                 x = _ln(self.layernorm, x)
         cache.pos = pos + 1
         return x
+
+    def token_head_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor, head: nn.Linear) -> torch.Tensor:
+        """``head(forward_step(...))`` with the final LayerNorm of a pre-LN stack folded into the head's product (one launch)."""
+        x = self.forward_step(tgt, cache, beam_idx, _skip_final_ln=True)
+        with torch.no_grad():
+            return Fn.decode_linear(x, [head.weight], [head.bias], ln=self.layernorm if self.layernorm_first else None)
