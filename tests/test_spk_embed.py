@@ -132,7 +132,8 @@ def test_fastspeech2_decoder_applies_the_speaker_vectors_first():
             enc2, _ = with_spk.spk_emb.combine_spk_feat(spk_feat=pre, spk_feat_lookup=look, enc_output=enc)
             b = plain(enc_text=enc2, enc_text_mask=mask, min_frame_num=0)
         assert torch.equal(a[2], b[2]) and torch.allclose(a[0].float(), b[0].float(), atol=1e-5) and torch.allclose(a[1].float(), b[1].float(), atol=1e-5)
-        assert not torch.allclose(a[0].float(), plain(enc_text=enc, enc_text_mask=mask, min_frame_num=0)[0].float(), atol=1e-3)  # (the speaker vectors matter)
+        c = plain(enc_text=enc, enc_text_mask=mask, min_frame_num=0)[0].float()  # (the speaker vectors matter: other durations or other frames)
+        assert c.shape != a[0].shape or not torch.allclose(a[0].float(), c, atol=1e-3)
     finally:
         Fn.set_compute_dtype(None)
         Fn.weights.invalidate()
