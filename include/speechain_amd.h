@@ -443,6 +443,15 @@ int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const long long*
                long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, const float* alpha,
                const float* nll, const float* gscale, float* beta, void* grad, hipStream_t stream);
 
+/* The same in two launches for a training step: sc_ctc_fwd_train runs the alpha AND the beta recursion in one launch of 2 B workgroups (they
+ * are independent, and each is one serial chain of frames per utterance), sc_ctc_grad then only writes the gradient rows from both. */
+int sc_ctc_fwd_train(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+                     long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, float* alpha,
+                     float* beta, float* nll, hipStream_t stream);
+int sc_ctc_grad(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+                long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, const float* alpha,
+                const float* beta, const float* nll, const float* gscale, void* grad, hipStream_t stream);
+
 /* dtype casts (0 = f32, 1 = bf16) and the transposed cast out[c][r] = in[r][c] of an (R, C) f32 matrix. */
 int sc_cast(int dtype_in, int dtype_out, const void* in, void* out, long long n, hipStream_t stream);
 /* Zero-padded row image of a (B, T, C) bf16 tensor: rows_total rows of C, utterance b at rows b (T + 2 r) .. with r zero rows on either side,

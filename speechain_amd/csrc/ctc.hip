@@ -79,10 +79,8 @@ __device__ __forceinline__ void ctc_gather(const CtcArgs& p, long long lbase, in
 }
 
 template <typename T, int NSPT>
-__global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
-  __shared__ int ext[kMaxS];
-  __shared__ float buf[2][kMaxS];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void ctc_alpha_body(const CtcArgs& p, const int b, int* ext, float (*buf)[kMaxS]) {
+  const int tid = threadIdx.x;
   const int L = (int)p.tgt_len[b];
   const int S = 2 * L + 1;
   const int Tb = (int)min((long long)p.Tmax, p.in_len[b]);
@@ -164,11 +162,8 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
 
 // beta_t(s) (with the emission at t) for t = Tb-1 .. 0 into p.beta (B, Tmax, Smax); same structure as the alpha kernel
 template <typename T, int NSPT>
-__global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
-  __shared__ int ext[kMaxS];
-  __shared__ float buf[2][kMaxS];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (p.gscale[b] == 0.f) return;  // infinite loss (zero_infinity) or zero upstream gradient: the gradient is all zeros
+__device__ __forceinline__ void ctc_beta_body(const CtcArgs& p, const int b, int* ext, float (*buf)[kMaxS]) {
+  const int tid = threadIdx.x;
   const int L = (int)p.tgt_len[b];
   const int S = 2 * L + 1;
   const int Tb = (int)min((long long)p.Tmax, p.in_len[b]);
@@ -235,6 +230,31 @@ __global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
 #undef CTC_BETA_FRAME
 }
 
+template <typename T, int NSPT>
+__global__ __launch_bounds__(256) void ctc_alpha_kernel(CtcArgs p) {
+  __shared__ int ext[kMaxS];
+  __shared__ float buf[2][kMaxS];
+  ctc_alpha_body<T, NSPT>(p, blockIdx.x, ext, buf);
+}
+
+template <typename T, int NSPT>
+__global__ __launch_bounds__(256) void ctc_beta_kernel(CtcArgs p) {
+  __shared__ int ext[kMaxS];
+  __shared__ float buf[2][kMaxS];
+  if (p.gscale[blockIdx.x] == 0.f) return;  // infinite loss (zero_infinity) or zero upstream gradient: the gradient is all zeros
+  ctc_beta_body<T, NSPT>(p, blockIdx.x, ext, buf);
+}
+
+// Both recursions of a training step in ONE launch of 2 B workgroups (they are independent and each is a serial chain of Tb frames on one
+// workgroup: launched one after the other they cost two chains, together one).  Workgroups [0, B) run alpha, [B, 2B) beta.
+template <typename T, int NSPT>
+__global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(CtcArgs p) {
+  __shared__ int ext[kMaxS];
+  __shared__ float buf[2][kMaxS];
+  if ((int)blockIdx.x < p.B) ctc_alpha_body<T, NSPT>(p, blockIdx.x, ext, buf);
+  else ctc_beta_body<T, NSPT>(p, (int)blockIdx.x - p.B, ext, buf);
+}
+
 // One workgroup per frame (b, t): the whole gradient row.
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs p) {
@@ -247,8 +267,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float g = (t < p.in_len[b]) ? p.gscale[b] : 0.f;
   const long long base = row * p.V;
+  // bf16 rows of a multiple of 8 classes move as 16-byte pieces (a 2-byte access per lane and instruction is instruction-bound)
+  const bool vec = sizeof(T) == 2 && (p.V & 7) == 0;
   if (g == 0.f) {
-    for (int v = tid; v < p.V; v += 256) Lg<T>::st(p.grad, base + v, 0.f);
+    if (vec) {
+      uint4* gr = reinterpret_cast<uint4*>((unsigned short*)p.grad + base);
+      for (int c = tid; c < (p.V >> 3); c += 256) gr[c] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int v = tid; v < p.V; v += 256) Lg<T>::st(p.grad, base + v, 0.f);
+    }
     return;
   }
   const int L = (int)p.tgt_len[b];
@@ -299,6 +326,30 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs p) {
     }
   }
   // every other class: g * softmax
+  if (vec) {
+    const uint4* lg = reinterpret_cast<const uint4*>((const unsigned short*)p.logits + base);
+    unsigned short* gr = (unsigned short*)p.grad + base;
+    for (int c = tid; c < (p.V >> 3); c += 256) {
+      const uint4 u = lg[c];
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+      const unsigned bits = (islabel[c >> 2] >> ((c & 3) * 8)) & 0xFFu;  // the piece's 8 classes lie in one bitmap word
+      unsigned short o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e] = sc_f32_to_bf16(g * expf(__uint_as_float(w[e] << 16) - lt));
+        o[2 * e + 1] = sc_f32_to_bf16(g * expf(__uint_as_float(w[e] & 0xffff0000u) - lt));
+      }
+      if (bits == 0u) {
+        *reinterpret_cast<uint4*>(gr + 8 * c) = make_uint4(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16),
+                                                           o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16));
+      } else {  // label columns are written by the threads above
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!((bits >> e) & 1u)) gr[8 * c + e] = o[e];
+      }
+    }
+    return;
+  }
   for (int v = tid; v < p.V; v += 256)
     if (!((islabel[v >> 5] >> (v & 31)) & 1u)) Lg<T>::st(p.grad, base + v, g * expf(Lg<T>::ld(p.logits, base + v) - lt));
 }
@@ -313,20 +364,46 @@ SC_API int sc_ctc_fwd(int dtype, const void* logits, const float* lse, const lon
   SC_CHECK_ARG(blank >= 0 && blank < V, "sc_ctc_fwd: blank %d outside the vocabulary", blank);
   CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, alpha, nll, nullptr, nullptr};
   // NSPT = extended-label positions per thread the recursion kernels are instantiated for (Smax <= 256 NSPT)
-#define SC_CTC_RECURSION(KERNEL)                                                                                             \
+#define SC_CTC_RECURSION(KERNEL, NB)                                                                                           \
   do {                                                                                                                       \
     if (dtype == 0) {                                                                                                        \
-      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<float, 1>), dim3(B), dim3(256), 0, stream, a);                              \
-      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<float, 2>), dim3(B), dim3(256), 0, stream, a);                         \
-      else hipLaunchKernelGGL((KERNEL<float, 4>), dim3(B), dim3(256), 0, stream, a);                                          \
+      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<float, 1>), dim3(NB), dim3(256), 0, stream, a);                              \
+      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<float, 2>), dim3(NB), dim3(256), 0, stream, a);                         \
+      else hipLaunchKernelGGL((KERNEL<float, 4>), dim3(NB), dim3(256), 0, stream, a);                                          \
     } else {                                                                                                                 \
-      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<unsigned short, 1>), dim3(B), dim3(256), 0, stream, a);                     \
-      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<unsigned short, 2>), dim3(B), dim3(256), 0, stream, a);                \
-      else hipLaunchKernelGGL((KERNEL<unsigned short, 4>), dim3(B), dim3(256), 0, stream, a);                                 \
+      if (Smax <= 256) hipLaunchKernelGGL((KERNEL<unsigned short, 1>), dim3(NB), dim3(256), 0, stream, a);                     \
+      else if (Smax <= 512) hipLaunchKernelGGL((KERNEL<unsigned short, 2>), dim3(NB), dim3(256), 0, stream, a);                \
+      else hipLaunchKernelGGL((KERNEL<unsigned short, 4>), dim3(NB), dim3(256), 0, stream, a);                                 \
     }                                                                                                                        \
   } while (0)
-  SC_CTC_RECURSION(ctc_alpha_kernel);
+  SC_CTC_RECURSION(ctc_alpha_kernel, B);
   SC_LAUNCH_CHECK("ctc_alpha_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_ctc_fwd_train(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+                            long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, float* alpha,
+                            float* beta, float* nll, hipStream_t stream) {
+  SC_CHECK_ARG(logits && lse && in_len && tgt && tgt_len && alpha && beta && nll, "sc_ctc_fwd_train: null pointer");
+  SC_CHECK_ARG(B >= 1 && Tmax >= 1 && V >= 1 && Smax >= 1 && Smax <= kMaxS, "sc_ctc_fwd_train: bad sizes (Smax=%d, limit %d)", Smax, kMaxS);
+  SC_CHECK_ARG(blank >= 0 && blank < V, "sc_ctc_fwd_train: blank %d outside the vocabulary", blank);
+  CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, alpha, nll, nullptr, nullptr, beta};
+  SC_CTC_RECURSION(ctc_alpha_beta_kernel, 2 * B);
+  SC_LAUNCH_CHECK("ctc_alpha_beta_kernel");
+  return SC_OK;
+}
+
+SC_API int sc_ctc_grad(int dtype, const void* logits, const float* lse, const long long* in_len, const long long* tgt,
+                       long long tgt_stride, const long long* tgt_len, int B, int Tmax, int V, int Smax, int blank, const float* alpha,
+                       const float* beta, const float* nll, const float* gscale, void* grad, hipStream_t stream) {
+  SC_CHECK_ARG(logits && lse && in_len && tgt && tgt_len && alpha && nll && gscale && beta && grad, "sc_ctc_grad: null pointer");
+  SC_CHECK_ARG(B >= 1 && Tmax >= 1 && V >= 1 && Smax >= 1 && Smax <= kMaxS, "sc_ctc_grad: bad sizes");
+  SC_CHECK_ARG(V <= (1 << 16), "sc_ctc_grad: vocabulary %d > 65536 (label bitmap in LDS)", V);
+  CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, const_cast<float*>(alpha), const_cast<float*>(nll), gscale, grad,
+            const_cast<float*>(beta)};
+  if (dtype == 0) hipLaunchKernelGGL(ctc_grad_kernel<float>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(ctc_grad_kernel<unsigned short>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
+  SC_LAUNCH_CHECK("ctc_grad_kernel");
   return SC_OK;
 }
 
@@ -338,10 +415,10 @@ SC_API int sc_ctc_bwd(int dtype, const void* logits, const float* lse, const lon
   SC_CHECK_ARG(V <= (1 << 16), "sc_ctc_bwd: vocabulary %d > 65536 (label bitmap in LDS)", V);
   CtcArgs a{logits, lse, in_len, tgt, tgt_stride, tgt_len, B, Tmax, V, Smax, blank, const_cast<float*>(alpha), const_cast<float*>(nll), gscale, grad, beta};
   if (dtype == 0) {
-    SC_CTC_RECURSION(ctc_beta_kernel);
+    SC_CTC_RECURSION(ctc_beta_kernel, B);
     hipLaunchKernelGGL(ctc_grad_kernel<float>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   } else {
-    SC_CTC_RECURSION(ctc_beta_kernel);
+    SC_CTC_RECURSION(ctc_beta_kernel, B);
     hipLaunchKernelGGL(ctc_grad_kernel<unsigned short>, dim3((unsigned)((long long)B * Tmax)), dim3(256), 0, stream, a);
   }
   SC_LAUNCH_CHECK("ctc backward kernels");

@@ -218,9 +218,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
   }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min(R, r0 + rows_per_block);
+  // A wave's rows are a serial chain of (load, two reductions, store): the next row's pieces are requested before the current row is
+  // reduced, so that a row costs its arithmetic instead of a memory round trip.
+  uint4 nd[NV], nx[NV], nr[NV];
+  float nmu = 0.f, nrs = 0.f;
+#define LN_BWD_REQUEST(ROW)                                                             \
+  do {                                                                                  \
+    const long long nb_ = (ROW) * D;                                                    \
+    nmu = mean[(ROW)];                                                                  \
+    nrs = rstd[(ROW)];                                                                  \
+    _Pragma("unroll") for (int c = 0; c < NV; ++c) {                                    \
+      const int k = 8 * (lane + 64 * c);                                                \
+      if (k < D) {                                                                      \
+        nd[c] = *reinterpret_cast<const uint4*>(dy + nb_ + k);                          \
+        nx[c] = *reinterpret_cast<const uint4*>(x + nb_ + k);                           \
+        if (dres) nr[c] = *reinterpret_cast<const uint4*>(dres + nb_ + k);              \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
+  if (r0 + wid < r1) LN_BWD_REQUEST(r0 + wid);
   for (long long row = r0 + wid; row < r1; row += 4) {
     const long long base = row * D;
-    const float mu = mean[row], rs = rstd[row];
+    const float mu = nmu, rs = nrs;
+    uint4 cd[NV], cx[NV], cr[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      cd[c] = nd[c];
+      cx[c] = nx[c];
+      cr[c] = nr[c];
+    }
+    if (row + 4 < r1) LN_BWD_REQUEST(row + 4);
     float g[NV][8], xh[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -228,8 +255,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
       const int k = 8 * (lane + 64 * c);
       if (k < D) {
         float d[8];
-        ln_unpack8(*reinterpret_cast<const uint4*>(dy + base + k), d);
-        ln_unpack8(*reinterpret_cast<const uint4*>(x + base + k), xh[c]);
+        ln_unpack8(cd[c], d);
+        ln_unpack8(cx[c], xh[c]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[c][e] = (xh[c][e] - mu) * rs;
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
       const int k = 8 * (lane + 64 * c);
       if (k < D) {
         float o[8], rv[8];
-        if (dres) ln_unpack8(*reinterpret_cast<const uint4*>(dres + base + k), rv);
+        if (dres) ln_unpack8(cr[c], rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rs * (g[c][e] - s1 - xh[c][e] * s2) + (dres ? rv[e] : 0.f);
         const uint4 packed = ln_pack8(o);
@@ -273,6 +300,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const unsigned s
       }
     }
   }
+#undef LN_BWD_REQUEST
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
     const int k = 8 * (lane + 64 * c);
@@ -700,6 +728,38 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const void* logits, long l
   }
 }
 
+// bf16 rows in 16-byte pieces (V, ld multiples of 8): one running (max, sum) pair per lane, rescaled once per piece
+__global__ __launch_bounds__(256) void row_lse_vec_kernel(const unsigned short* logits, int V, long long ld, float* lse_out) {
+  __shared__ float sm[2][4];
+  const uint4* row = reinterpret_cast<const uint4*>(logits + (long long)blockIdx.x * ld);
+  float mx = -INFINITY, se = 0.f;
+  for (int c = threadIdx.x; c < (V >> 3); c += 256) {
+    float f[8];
+    ln_unpack8(row[c], f);
+    float cm = f[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) cm = fmaxf(cm, f[e]);
+    if (cm > mx) {
+      se *= expf(mx - cm);  // (exp(-inf) = 0 on the first piece)
+      mx = cm;
+    }
+    if (mx != -INFINITY)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) se += expf(f[e] - mx);
+  }
+  const float wmx = sc_wave_max(mx);
+  se = sc_wave_sum(mx == -INFINITY ? 0.f : se * expf(mx - wmx));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sm[0][wid] = wmx; sm[1][wid] = se; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gm = fmaxf(fmaxf(sm[0][0], sm[0][1]), fmaxf(sm[0][2], sm[0][3]));
+    float gs = 0.f;
+    for (int w = 0; w < 4; ++w) gs += sm[0][w] == -INFINITY ? 0.f : sm[1][w] * expf(sm[0][w] - gm);
+    lse_out[blockIdx.x] = gm + logf(gs);
+  }
+}
+
 }  // namespace
 
 #define SC_DISPATCH_TN(dtype, n, KERNEL, N0, N1, N2, ...)                                                  \
@@ -925,7 +985,10 @@ SC_API int sc_ce_bwd(int dtype, const void* logits, const long long* target, con
 SC_API int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream) {
   SC_CHECK_ARG(logits && lse, "sc_row_lse: null pointer");
   SC_CHECK_ARG(R >= 1 && V >= 1 && ld >= V, "sc_row_lse: bad sizes");
-  SC_DISPATCH_T(dtype, row_lse_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, R, V, ld, lse);
+  if (dtype == 1 && (V & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)logits & 15) == 0)
+    hipLaunchKernelGGL(row_lse_vec_kernel, dim3((unsigned)R), dim3(256), 0, stream, (const unsigned short*)logits, V, ld, lse);
+  else
+    SC_DISPATCH_T(dtype, row_lse_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, R, V, ld, lse);
   SC_LAUNCH_CHECK("row_lse_kernel");
   return SC_OK;
 }

@@ -46,16 +46,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
-// 64-lane wavefront reductions (butterfly over DPP/ds_swizzle as the compiler chooses).
+// 64-lane wavefront reductions on the DPP data path (v_add_f32_dpp / v_max_f32_dpp: quad permutes, half-row and row mirrors, then the
+// row broadcasts 15 and 31 and a v_readlane of lane 63): ~8 VALU instructions.  The __shfl_xor butterfly compiles to six DEPENDENT
+// ds_bpermute_b32 round trips through the LDS crossbar -- the serial part of every row kernel (two reductions per LayerNorm row).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sc_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float sc_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += sc_dpp<0xB1, 0xF>(0.f, v);   // quad_perm [1,0,3,2]
+  v += sc_dpp<0x4E, 0xF>(0.f, v);   // quad_perm [2,3,0,1]
+  v += sc_dpp<0x141, 0xF>(0.f, v);  // row_half_mirror
+  v += sc_dpp<0x140, 0xF>(0.f, v);  // row_mirror: every lane holds the sum of its row of 16
+  v += sc_dpp<0x142, 0xA>(0.f, v);  // row_bcast15 into rows 1 and 3
+  v += sc_dpp<0x143, 0xC>(0.f, v);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float sc_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, sc_dpp<0xB1, 0xF>(v, v));
+  v = fmaxf(v, sc_dpp<0x4E, 0xF>(v, v));
+  v = fmaxf(v, sc_dpp<0x141, 0xF>(v, v));
+  v = fmaxf(v, sc_dpp<0x140, 0xF>(v, v));
+  v = fmaxf(v, sc_dpp<0x142, 0xA>(v, v));
+  v = fmaxf(v, sc_dpp<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // bf16 <-> f32 (round-to-nearest-even through the hardware convert; keeps NaN a NaN).

@@ -1499,9 +1499,15 @@ class _CTC(torch.autograd.Function):
         lib.call("sc_row_lse", dcode(logits), _p(logits), B * T, V, V, _p(lse), stream())
         alpha = torch.empty(B, T, Smax, dtype=torch.float32, device=dev)
         nll = torch.empty(B, dtype=torch.float32, device=dev)
-        lib.call("sc_ctc_fwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax,
-                 blank, _p(alpha), _p(nll), stream())
-        ctx.save_for_backward(logits, lse, in_len, tgt, tgt_len, alpha, nll)
+        if ctx.needs_input_grad[0]:  # a training step: both recursions in one launch (each is one serial chain of frames per utterance)
+            beta = torch.empty_like(alpha)
+            lib.call("sc_ctc_fwd_train", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax,
+                     blank, _p(alpha), _p(beta), _p(nll), stream())
+            ctx.save_for_backward(logits, lse, in_len, tgt, tgt_len, alpha, nll, beta)
+        else:
+            lib.call("sc_ctc_fwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax,
+                     blank, _p(alpha), _p(nll), stream())
+            ctx.save_for_backward(logits, lse, in_len, tgt, tgt_len, alpha, nll)
         ctx.meta = (blank, zero_infinity, Smax)
         if zero_infinity:
             return torch.where(torch.isinf(nll), torch.zeros_like(nll), nll)
@@ -1509,13 +1515,17 @@ class _CTC(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        logits, lse, in_len, tgt, tgt_len, alpha, nll = ctx.saved_tensors
+        logits, lse, in_len, tgt, tgt_len, alpha, nll = ctx.saved_tensors[:7]
         blank, zero_infinity, Smax = ctx.meta
         B, T, V = logits.shape
         gscale = g.float().contiguous()
         if zero_infinity:
             gscale = torch.where(torch.isinf(nll), torch.zeros_like(gscale), gscale)
         grad = torch.empty_like(logits)
+        if len(ctx.saved_tensors) == 8:  # beta came with the forward pass (sc_ctc_fwd_train)
+            lib.call("sc_ctc_grad", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax, blank,
+                     _p(alpha), _p(ctx.saved_tensors[7]), _p(nll), _p(gscale), _p(grad), stream())
+            return grad, None, None, None, None, None
         beta = torch.empty_like(alpha)  # (B, T, Smax) workspace of the backward recursion
         lib.call("sc_ctc_bwd", dcode(logits), _p(logits), _p(lse), _p(in_len), _p(tgt), tgt.stride(0), _p(tgt_len), B, T, V, Smax, blank,
                  _p(alpha), _p(nll), _p(gscale), _p(beta), _p(grad), stream())

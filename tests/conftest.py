@@ -46,3 +46,13 @@ def golden():
         return cache[name]
 
     return get
+
+
+@pytest.fixture(autouse=True)
+def _reset_functional_state():
+    """The process-wide switches of speechain_amd.functional go back to their defaults after every test, also after a failing one."""
+    yield
+    fn = sys.modules.get("speechain_amd.functional")
+    if fn is not None:
+        fn.set_compute_dtype(None)
+        fn.set_attention_probs(True)

