@@ -15,6 +15,7 @@ feature-normalisation statistics and the BatchNorm statistics (SyncBatchNorm, as
                   bounded sample of the same workload (rank 0, N = 1 only)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -988,19 +989,28 @@ def main():
         wl = ASRTrainStepWorkload(device, rank, world, prenet_dims, distributed=dist is not None)
     for _ in range(args.warmup):
         wl.step(False)
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A full (generation-2) pass of Python's cyclic collector over the heap this process has built by now takes ~40 ms, and the allocation
+    # counters reach its threshold some tens of steps into the timed region (seen as one 40 ms step in the 0.08 ms frontend workload): collect
+    # now and move the survivors out of the collector's reach, as a long-running training process would at start-up.
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
+    dbg = [] if os.environ.get("BENCH_DEBUG_STEPS") else None  # (host time of every timed step and of the final drain, to stderr)
     for i in range(args.steps):
         wl.step(True)  # every timed step is the same replayed step
+        if dbg is not None:
+            dbg.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
+    if dbg is not None and rank == 0:
+        print("host us per timed step:", [round(1e6 * (b - a)) for a, b in zip([t0] + dbg[:-1], dbg)], "drain us:", round(1e6 * (t0 + elapsed - dbg[-1])), file=sys.stderr)
     if args.workload in ("asr_train_step", "tts_train_step", "asr_decode"):
         # one more step, eager, with HIP events around every GEMM launch: the roofline's per-kernel times.  It runs right AFTER the timed
         # region (it takes about twice a replayed step and, on several ranks, uses the hook-launched all-reduce path), in the same

@@ -206,6 +206,13 @@ int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, i
                    const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                    const long long* time_pos, int nt, const float* fill, hipStream_t stream);
 
+/* The same with the mean of the WARPED features as fill value (specaug.py:203, feat_norm off) in one call of two launches: the first warps
+ * and leaves one sum per workgroup in `workspace` (sc_specaug_meanfill_workspace bytes), the second masks in place with their total / (B T F). */
+long long sc_specaug_meanfill_workspace(int B, int T);
+int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+                            const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
+                            const long long* time_pos, int nt, void* workspace, long long ws_bytes, hipStream_t stream);
+
 /* ---- transformer primitives -------------------------------------------------------------------------------
  * `dtype` selects the activation type of a call: 0 = float32 (exact-f32 matrix cores, parity path),
  * 1 = bfloat16 (bf16 matrix cores with f32 accumulation, training path).  Statistics, biases, gammas, losses and

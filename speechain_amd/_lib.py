@@ -112,7 +112,9 @@ def ptr(t):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of the current HIP stream of the current device (the two C calls below: ~0.3 us; ``torch.cuda.current_stream().cuda_stream``
+    builds a Python stream object on every call: ~2.5 us, once per kernel launch on the host-bound paths)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def require_gpu(t: torch.Tensor, what: str):

@@ -26,6 +26,10 @@ struct SpecAugArgs {
   const long long* time_pos;
   int nt;
   const float* fill;          // device scalar or null (fill = 0)
+  double* partial_out;        // per-workgroup sum of the written elements (pass 1 of sc_specaug_fwd_meanfill) or null
+  const double* partial_in;   // the partial sums of pass 1: fill = their total * inv_count (pass 2) or null
+  int n_partial;
+  double inv_count;
 };
 
 __device__ __forceinline__ float cubic_inner(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
@@ -55,8 +59,21 @@ __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
     }
     fm[f] = m ? 1 : 0;
   }
+  __shared__ double red[256];
+  if (p.partial_in) {  // fill = mean of the warped features (specaug.py:203), from the per-workgroup sums of the first pass
+    double s = 0.0;
+    for (int i = tid; i < p.n_partial; i += 256) s += p.partial_in[i];
+    red[tid] = s;
+  }
   __syncthreads();
-  const float fillv = p.fill ? *p.fill : 0.f;
+  if (p.partial_in) {
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+  }
+  const float fillv = p.partial_in ? (float)(red[0] * p.inv_count) : (p.fill ? *p.fill : 0.f);
+  float wsum = 0.f;
   const int FQ = (p.F + 3) >> 2;                 // column quads per row
   const int lanes = max(1, 256 / FQ);            // rows in flight
   const int q = tid % FQ, rl = tid / FQ;
@@ -129,7 +146,19 @@ __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
       float* dp = p.out + ((long long)b * p.T + t) * p.F + f0;
       if (vec) *reinterpret_cast<float4*>(dp) = make_float4(v[0], v[1], v[2], v[3]);
       else { for (int e = 0; e < nc; ++e) dp[e] = v[e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wsum += e < nc ? v[e] : 0.f;
     }
+  }
+  if (p.partial_out) {  // (<= 128 elements per thread in float, the workgroup's and the grid's totals in double)
+    __syncthreads();
+    red[tid] = (double)wsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) p.partial_out[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
   }
 }
 
@@ -179,6 +208,46 @@ SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int 
   dim3 grid(sc_cdiv(T, kRowsPerBlock), B);
   hipLaunchKernelGGL(specaug_kernel, grid, dim3(256), 0, stream, a);
   SC_LAUNCH_CHECK("specaug_kernel");
+  return SC_OK;
+}
+
+SC_API long long sc_specaug_meanfill_workspace(int B, int T) { return (long long)sc_cdiv(T, kRowsPerBlock) * B * (long long)sizeof(double); }
+
+// Warp, then mask with the mean of the warped features as fill value (specaug.py:111-124, :160-204 with feat_norm off) in one call: pass 1
+// warps in -> out and leaves one sum per workgroup, pass 2 masks out in place and every workgroup totals the sums for its fill value.
+SC_API int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+                                   const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
+                                   const long long* time_pos, int nt, void* workspace, long long ws_bytes, hipStream_t stream) {
+  SC_CHECK_ARG(in && out && workspace, "sc_specaug_fwd_meanfill: null pointer");
+  SC_CHECK_ARG(in != out, "sc_specaug_fwd_meanfill: not in place");
+  SC_CHECK_ARG(B >= 1 && T >= 1 && F >= 1 && F <= kMaxF, "sc_specaug_fwd_meanfill: bad shape (%d,%d,%d)", B, T, F);
+  SC_CHECK_ARG(nf == 0 || (freq_len && freq_pos), "sc_specaug_fwd_meanfill: nf=%d without index tensors", nf);
+  SC_CHECK_ARG(nt == 0 || (time_len && time_pos), "sc_specaug_fwd_meanfill: nt=%d without index tensors", nt);
+  SC_CHECK_ARG(nf <= kMaxMasks * 64 && nt <= kMaxMasks * 64, "sc_specaug_fwd_meanfill: too many masks");
+  SC_CHECK_ARG(ws_bytes >= sc_specaug_meanfill_workspace(B, T), "sc_specaug_fwd_meanfill: workspace too small");
+  SpecAugArgs a{};
+  a.in = in; a.out = out; a.B = B; a.T = T; a.F = F; a.tmin = tmin;
+  a.warp_center = warp_center; a.warp_pos = warp_pos;
+  if (warp_center >= 0) {
+    SC_CHECK_ARG(warp_pos >= 1 && warp_pos < tmin && warp_center >= 1 && warp_center < tmin && tmin <= T,
+                 "sc_specaug_fwd_meanfill: bad warp (center=%d pos=%d tmin=%d T=%d)", warp_center, warp_pos, tmin, T);
+    const int lo = warp_pos, ro = tmin - warp_pos;
+    a.scale_l = lo > 1 ? (float)((double)(warp_center - 1) / (double)(lo - 1)) : 0.f;
+    a.scale_r = ro > 1 ? (float)((double)(tmin - warp_center - 1) / (double)(ro - 1)) : 0.f;
+  }
+  dim3 grid(sc_cdiv(T, kRowsPerBlock), B);
+  a.partial_out = (double*)workspace;
+  hipLaunchKernelGGL(specaug_kernel, grid, dim3(256), 0, stream, a);
+  SpecAugArgs m{};
+  m.in = out; m.out = out; m.B = B; m.T = T; m.F = F; m.tmin = tmin;
+  m.warp_center = m.warp_pos = -1;
+  m.freq_len = freq_len; m.freq_pos = freq_pos; m.nf = nf;
+  m.time_len = time_len; m.time_pos = time_pos; m.nt = nt;
+  m.partial_in = (const double*)workspace;
+  m.n_partial = (int)(grid.x * grid.y);
+  m.inv_count = 1.0 / ((double)B * T * F);
+  hipLaunchKernelGGL(specaug_kernel, grid, dim3(256), 0, stream, m);
+  SC_LAUNCH_CHECK("specaug_kernel (mean fill)");
   return SC_OK;
 }
 

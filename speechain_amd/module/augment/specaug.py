@@ -84,6 +84,19 @@ class SpecAugment(Module):
                                           size=(batch_size, self.time_mask_num), device=device)
         return d
 
+    def _staging(self, n: int):
+        """(pinned int64 buffer of >= n elements, its event) from a ring of eight: the host runs ahead of the device, so a buffer is reused
+        only once the copy that read it last has completed."""
+        ring = self.__dict__.get("_ring")
+        if ring is None or ring[0][0].numel() < n:
+            ring = [(torch.empty(max(n, 256), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self.__dict__["_ring"], self.__dict__["_ring_at"] = ring, 0
+        at = self.__dict__["_ring_at"] = (self.__dict__["_ring_at"] + 1) % len(ring)
+        pin, ev = ring[at]
+        if not ev.query():  # (True for an event never recorded or long complete)
+            ev.synchronize()
+        return pin, ev
+
     def apply(self, feat: torch.Tensor, draws: Dict) -> torch.Tensor:
         """Warp + mask + fill on the device for given indices (``draws`` as returned by :meth:`draw`)."""
         require_gpu(feat, "SpecAugment")
@@ -92,31 +105,43 @@ class SpecAugment(Module):
         dev = x.device
         idx = [draws["freq_len"], draws["freq_pos"], draws["time_len"], draws["time_pos"]]
         host = [t for t in idx if t is not None and not t.is_cuda]
-        if len(host) > 1:  # host-side draws: one pinned staging buffer, one copy, four views
-            flat = torch.cat([t.reshape(-1).to(torch.int64) for t in host]).pin_memory().to(dev, non_blocking=True)
-            off = 0
-            for i, t in enumerate(idx):
+        if len(host) > 1:
+            # host-side draws: the four tensors go into one pinned staging buffer (from a ring: the kernels run later) which the kernels read
+            # in place -- pinned host memory is device-addressable, and ~1 KB read once per workgroup costs less than an asynchronous copy call
+            n = sum(t.numel() for t in host)
+            pin, done = self._staging(n)
+            torch.cat([t.reshape(-1) if t.dtype == torch.int64 else t.reshape(-1).to(torch.int64) for t in host], out=pin[:n])
+            base, off, staged = pin.data_ptr(), 0, []
+            for t in idx:
                 if t is not None and not t.is_cuda:
-                    idx[i] = flat[off: off + t.numel()].view(t.shape)
+                    staged.append((base + 8 * off, t.size(1)))
                     off += t.numel()
-        i64 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int64).contiguous()
-        fl, fp, tl, tp = (i64(t) for t in idx)
-        nf = 0 if fl is None else fl.size(1)
-        nt = 0 if tl is None else tl.size(1)
+                else:
+                    staged.append(None)
+        else:
+            staged, done = [None] * 4, None
+        i64 = lambda t: t if t is None or (t.device == dev and t.dtype == torch.int64 and t.is_contiguous()) else t.to(device=dev, dtype=torch.int64).contiguous()
+        keep = [None if st is not None else i64(t) for t, st in zip(idx, staged)]  # (device-side draws: the tensors themselves)
+        addr = [st[0] if st is not None else ptr(k) for k, st in zip(keep, staged)]
+        width = [st[1] if st is not None else (0 if k is None else k.size(1)) for k, st in zip(keep, staged)]
+        fl, fp, tl, tp = addr
+        nf, nt = width[0], width[2]
         c = -1 if draws["warp_center"] is None else int(draws["warp_center"])
         p = -1 if draws["warp_pos"] is None else int(draws["warp_pos"])
         out = torch.empty_like(x)
         tmin = int(draws["time_minlen"])
         masked = nf > 0 or nt > 0
         if masked and not self.feat_norm:
-            # fill value = mean of the (warped) features (specaug.py:203): warp first, reduce, then mask in place
-            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, None, None, 0, None, None, 0, None, stream())
-            fill = out.mean().reshape(1)
-            lib.call("sc_specaug_fwd", ptr(out), ptr(out), B, T, Fd, tmin, -1, -1, ptr(fl), ptr(fp), nf, ptr(tl), ptr(tp),
-                     nt, ptr(fill), stream())
+            # fill value = mean of the (warped) features (specaug.py:203): warp + per-workgroup sums, then masks in place (one call)
+            ws = self.__dict__.get("_meanfill_ws")
+            if ws is None or ws[0] != (B, T, dev):
+                ws = ((B, T, dev), torch.empty(lib.value("sc_specaug_meanfill_workspace", B, T), dtype=torch.uint8, device=dev))
+                self.__dict__["_meanfill_ws"] = ws  # (reused: the calls of one module are ordered on its stream)
+            lib.call("sc_specaug_fwd_meanfill", ptr(x), ptr(out), B, T, Fd, tmin, c, p, fl, fp, nf, tl, tp, nt, ptr(ws[1]), ws[1].numel(), stream())
         else:
-            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, ptr(fl), ptr(fp), nf, ptr(tl), ptr(tp), nt,
-                     None, stream())
+            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, fl, fp, nf, tl, tp, nt, None, stream())
+        if done is not None:
+            done.record()  # (the staging buffer is free once these kernels have run)
         return out
 
     def forward(self, feat: torch.Tensor, feat_len: torch.Tensor):
