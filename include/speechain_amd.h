@@ -416,6 +416,12 @@ int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals,
  * per sentence (infer_func/beam_search.py:401-410,455-462 read these on the host). */
 int sc_beam_pack(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, double* pack,
                  hipStream_t stream);
+/* sc_beam_pack plus the next step's rows made on the device (beam_search.py:423-509: a running sentence keeps its first `beam` candidates in
+ * rank order whose token is not <sos/eos>): scores / tokens / beam_idx (B * beam) are overwritten, prev_tokens receives this step's tokens.
+ * The host still reads the packed record for the n-best lists and the stopping rules, one step behind the device.  2 beam <= K <= 128. */
+int sc_beam_advance(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, int V,
+                    int eos_token, double* pack, float* scores, long long* tokens, long long* prev_tokens, long long* beam_idx,
+                    hipStream_t stream);
 int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, int K, int L, float* vals, long long* idx, hipStream_t stream);
 
 /* Candidate scores of a beam-search step (speechain/infer_func/beam_search.py:334-345,401-410) in one pass over the token head's logits:

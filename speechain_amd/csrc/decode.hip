@@ -795,6 +795,62 @@ SC_API int sc_beam_pack(const float* vals, const long long* idx, const float* eo
   return SC_OK;
 }
 
+namespace {
+// beam_pack_kernel plus the next step's rows of sentence b: the first `beam` candidates in rank order whose token is not <sos/eos>
+// (beam_search.py:423-509 keeps exactly those for a running sentence; a row holds one <sos/eos> column, so at most `beam` of the 2 beam
+// candidates are skipped).  prev_tokens <- tokens before tokens is overwritten.
+__global__ __launch_bounds__(256) void beam_advance_kernel(const float* vals, const long long* idx, const float* eos, const float* other, int K, int beam,
+                                                           double* pack, int width, int V, int eos_token, float* scores, long long* tokens,
+                                                           long long* prev_tokens, long long* beam_idx) {
+  __shared__ float sv[128];
+  __shared__ long long si[128];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* row = pack + (long long)b * width;
+  for (int i = tid; i < width; i += 256) {
+    double v;
+    if (i < K) v = (double)vals[(long long)b * K + i];
+    else if (i < 2 * K) v = (double)idx[(long long)b * K + i - K];
+    else if (i < 2 * K + beam) v = (double)eos[(long long)b * beam + i - 2 * K];
+    else v = (double)other[(long long)b * beam + i - 2 * K - beam];
+    row[i] = v;
+  }
+  if (tid < K) {
+    sv[tid] = vals[(long long)b * K + tid];
+    si[tid] = idx[(long long)b * K + tid];
+  }
+  if (tid < beam) prev_tokens[(long long)b * beam + tid] = tokens[(long long)b * beam + tid];
+  __syncthreads();
+  if (tid == 0) {
+    int kept = 0;
+    for (int i = 0; i < K && kept < beam; ++i) {
+      const long long id = si[i];
+      const int tok = (int)(id % V);
+      if (tok == eos_token) continue;
+      const long long r = (long long)b * beam + kept;
+      scores[r] = sv[i];
+      tokens[r] = tok;
+      beam_idx[r] = (long long)b * beam + id / V;
+      ++kept;
+    }
+  }
+}
+}  // namespace
+
+// sc_beam_pack and, in the same launch, the rows of the next step written on the device: scores / tokens / beam_idx (B * beam) <- the first
+// `beam` non-<sos/eos> candidates of every sentence in rank order, prev_tokens <- the tokens of this step.  The host reads the packed record
+// for its n-best lists and stopping rules while the device is already running the next position.  K <= 128, K >= 2 * beam.
+SC_API int sc_beam_advance(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, int V,
+                           int eos_token, double* pack, float* scores, long long* tokens, long long* prev_tokens, long long* beam_idx,
+                           hipStream_t stream) {
+  SC_CHECK_ARG(vals && idx && pack && scores && tokens && prev_tokens && beam_idx && ((eos == nullptr) == (other == nullptr)), "sc_beam_advance: null pointer");
+  SC_CHECK_ARG(B >= 1 && B <= 65535 && beam >= 1 && K >= 2 * beam && K <= 128 && V >= 2 && eos_token >= 0 && eos_token < V,
+               "sc_beam_advance: bad sizes (B=%d K=%d beam=%d V=%d)", B, K, beam, V);
+  hipLaunchKernelGGL(beam_advance_kernel, dim3(B), dim3(256), 0, stream, vals, idx, eos, other, K, beam, pack, 2 * K + (eos ? 2 * beam : 0), V,
+                     eos_token, scores, tokens, prev_tokens, beam_idx);
+  SC_LAUNCH_CHECK("beam_advance_kernel");
+  return SC_OK;
+}
+
 // vals / idx (R, K): the K largest elements of every row of x (R, L; row stride ld) in descending order, ties by the lower index.
 SC_API int sc_topk_rows(const float* x, long long ld, int R, int L, int K, float* vals, long long* idx, hipStream_t stream) {
   SC_CHECK_ARG(x && vals && idx, "sc_topk_rows: null pointer");

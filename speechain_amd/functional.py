@@ -2060,6 +2060,20 @@ def beam_pack(vals: torch.Tensor, idx: torch.Tensor, eos: Optional[torch.Tensor]
     lib.call("sc_beam_pack", _p(vals), _p(idx), _p(eos), _p(other), B, K, int(beam), _p(pack), stream())
 
 
+def beam_advance(vals, idx, eos, other, beam: int, V: int, eos_token: int, pack, scores, tokens, prev_tokens, beam_idx):
+    """`beam_pack` and the next step's rows in one launch (sc_beam_advance): scores / tokens / beam_idx <- the first `beam` candidates of every
+    sentence that are not <sos/eos>, prev_tokens <- tokens."""
+    B, K = vals.shape
+    assert pack.dtype == torch.float64 and pack.is_contiguous() and pack.shape == (B, 2 * K + (2 * beam if eos is not None else 0))
+    assert idx.dtype == torch.long and vals.dtype == torch.float32 and vals.is_contiguous() and idx.is_contiguous()
+    assert eos is None or (eos.dtype == torch.float32 and other.dtype == torch.float32 and eos.is_contiguous() and other.is_contiguous()
+                           and eos.numel() == B * beam == other.numel())
+    for t_, dt in ((scores, torch.float32), (tokens, torch.long), (prev_tokens, torch.long), (beam_idx, torch.long)):
+        assert t_.dtype == dt and t_.is_contiguous() and t_.numel() == B * beam
+    lib.call("sc_beam_advance", _p(vals), _p(idx), _p(eos), _p(other), B, K, int(beam), int(V), int(eos_token), _p(pack), _p(scores), _p(tokens),
+             _p(prev_tokens), _p(beam_idx), stream())
+
+
 _TOPK_TWO_STAGE = _os.environ.get("SC_TOPK_TWO_STAGE", "1") == "1"  # (A/B knob)
 
 

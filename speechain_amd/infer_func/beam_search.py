@@ -11,6 +11,11 @@ What differs underneath:
   * the CTC prefix scores come from ``sc_ctc_prefix_scores`` (no (T, 2, N, V) tensor, see ``infer_func/ctc_decoding.py``);
   * the step's bookkeeping reads ONE small device-to-host copy (the 2 x beam best candidates per sentence) where the reference reads a
     scalar per candidate (``.item()``, :446-506); hypotheses live on the host as integer arrays;
+  * with a cached decoder the rows of the next position (the first ``beam`` candidates of a sentence that are not <sos/eos>, :423-509) are
+    ALSO written on the device, in the launch that packs the record (``sc_beam_advance``): the device runs position p + 1 while the host
+    works through the record of position p -- n-best lists, <eos> filter, stopping rules, all as before and from the same numbers.  A sentence
+    the host has declared finished keeps decoding on the device until the batch ends; the host ignores its candidates, as the reference
+    ignores a finished sentence;
   * with a cached decoder the device side of a step -- ancestry table, 6 decoder layers, token head, log-softmax, CTC prefix scores,
     score mixing, top-k -- touches only buffers that live as long as the decode function and, from the second call on, is replayed from
     one hipGraph per position (``SC_DECODE_NO_GRAPH=1``: eager launches of the same code).
@@ -85,7 +90,10 @@ class _Session:
         self.pack = torch.zeros(B, (6 if eos_filtering else 4) * beam, dtype=torch.float64, device=dev)
         # pinned host mirrors: the step's record comes down and the next rows go up without pageable staging copies (each of those costs a
         # host-side allocation and a blocking transfer -- four per step)
-        self.pack_host = torch.zeros(self.pack.shape, dtype=torch.float64).pin_memory()
+        self.pack_host = [torch.zeros(self.pack.shape, dtype=torch.float64).pin_memory() for _ in range(2)]  # (position p -> mirror p & 1)
+        self.fetched = [torch.cuda.Event() for _ in range(2)]
+        # the next rows are chosen on the device (sc_beam_advance) when the two-stage top-k path runs; otherwise the host uploads them
+        self.ahead = 2 * beam <= 64 and os.environ.get("SC_DECODE_AHEAD", "1") == "1"  # (A/B knob: 0 = the host uploads the rows, step by step)
         self.up_scores = torch.zeros(N, dtype=torch.float32).pin_memory()
         self.up_tokens = torch.zeros(N, dtype=torch.long).pin_memory()
         self.up_parent = torch.zeros(N, dtype=torch.long).pin_memory()
@@ -148,6 +156,10 @@ class _Session:
             #  32 over 80 000; same result as one selection over the sentence's beam * V candidates, ties included)
             top_scores, top_ids = Fn.topk_groups(cand.view(B * beam, V), beam, 2 * beam) if 2 * beam <= 64 else \
                 torch.topk(cand.view(B, beam * V), 2 * beam, dim=1, largest=True, sorted=True)
+            if self.ahead:
+                Fn.beam_advance(top_scores, top_ids, eos_score if self.eos_filtering else None, other_max if self.eos_filtering else None, beam, V,
+                                self.sos_eos, self.pack, self.scores, self.tokens, self.prev_tokens, self.beam_idx)
+                return
             if top_scores.dtype == torch.float32 and top_scores.is_contiguous() and top_ids.is_contiguous():
                 Fn.beam_pack(top_scores, top_ids, eos_score if self.eos_filtering else None, other_max if self.eos_filtering else None, beam,
                              self.pack)  # (one launch instead of four casts, a cat and a copy)
@@ -158,8 +170,8 @@ class _Session:
                 self.pack.copy_(torch.cat(fetch, dim=1))
             self.prev_tokens.copy_(self.tokens)
 
-    def step(self, pos: int) -> np.ndarray:
-        """Runs position `pos` on the rows described by tokens / beam_idx / scores; returns the packed candidates on the host."""
+    def launch(self, pos: int):
+        """Enqueues position `pos` on the rows described by tokens / beam_idx / scores and the copy of its record to the host."""
         if self.use_graphs and REPLAY_GRAPHS and self.calls >= 2:  # (the first call runs eagerly: it also fills the cached bf16 weights)
             g = self.graphs.get(pos)
             if g is None:
@@ -173,9 +185,17 @@ class _Session:
             g.replay()
         else:
             self._device_step(pos)
-        self.pack_host.copy_(self.pack, non_blocking=True)  # the step's one device-to-host copy
-        torch.cuda.current_stream(self.dev).synchronize()
-        return self.pack_host.numpy().copy()
+        self.pack_host[pos & 1].copy_(self.pack, non_blocking=True)  # the step's one device-to-host copy
+        self.fetched[pos & 1].record()
+
+    def fetch(self, pos: int) -> np.ndarray:
+        """The packed candidates of position `pos` on the host (waits for that position's copy only)."""
+        self.fetched[pos & 1].synchronize()
+        return self.pack_host[pos & 1].numpy().copy()
+
+    def step(self, pos: int) -> np.ndarray:
+        self.launch(pos)
+        return self.fetch(pos)
 
     def upload(self, scores: np.ndarray, tokens: np.ndarray, parent: np.ndarray):
         """The next step's rows: host arrays -> pinned mirrors -> device, asynchronously (the mirrors are rewritten only after the next
@@ -297,8 +317,22 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
             return torch.cat([f.to(torch.float64) for f in fetch], dim=1).cpu().numpy()  # the step's one device-to-host copy
 
     step_no = 0
+    ahead = session is not None and session.ahead
+    launched = -1  # (the last position enqueued on the device)
+    final_scores_host = None
     while int(text_len.max()) < hypo_maxlen:
-        host = session.step(step_no) if session is not None else prefix_step()
+        if ahead:
+            # the device picks its own next rows: position step_no + 1 is enqueued before the host reads the record of step_no (every running row
+            # is step_no + 2 tokens long after this iteration, so a next iteration exists exactly when step_no + 2 < hypo_maxlen)
+            if launched < step_no:
+                session.launch(step_no)
+                launched = step_no
+            if step_no + 2 < hypo_maxlen:
+                session.launch(step_no + 1)
+                launched = step_no + 1
+            host = session.fetch(step_no)
+        else:
+            host = session.step(step_no) if session is not None else prefix_step()
         step_no += 1
         h_scores = host[:, :2 * beam_size].astype(np.float32)
         h_ids = host[:, 2 * beam_size:4 * beam_size].astype(np.int64)
@@ -341,6 +375,9 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
         # ---- the next step's rows ----
         text = np.concatenate([text[new_parent], new_tokens[:, None]], axis=1)
         text_len = (text != padding_idx).sum(-1)
+        if ahead:
+            final_scores_host = new_scores  # (the device rows are already a position further)
+            continue
         if session is not None:
             session.upload(new_scores, new_tokens, new_parent)
             beam_scores = session.scores
@@ -353,7 +390,7 @@ def beam_searching(enc_feat: torch.Tensor, enc_feat_mask: torch.Tensor, asr_deco
             ctc_memory = ctc_scorer.permute_mem(ctc_memory, beam_idx_dev, last_tokens.view(B, beam_size) + slot_offset)
 
     # ---- hypotheses cut by the length limit (:529-541) ----
-    final_scores = beam_scores.cpu().numpy()
+    final_scores = final_scores_host if final_scores_host is not None else beam_scores.cpu().numpy()
     for b in range(B):
         if done[b]:
             continue
