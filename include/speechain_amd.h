@@ -355,6 +355,12 @@ long long sc_attention_bwd_workspace(int B, int H, int Tq, int Tk);
 int sc_decode_linear(const void* x, long long ldx, int M, int K, const void* w, long long ldw, int N, const float* bias,
                      const float* ln_gamma, const float* ln_beta, float ln_eps, int act, const void* residual, long long ldr, void* y,
                      long long ldy, hipStream_t stream);
+/* The same with the LayerNorm applied through its row statistics: LN(x) W^T + b = rstd (x w_scaled^T - mean colsum) + shift with
+ * w_scaled[n][k] = bf16(gamma[k] W[n][k]), colsum[n] = sum_k w_scaled[n][k], shift = W beta + b (made once per weight version by the caller).
+ * The product reads the raw rows; the statistics (two-pass variance over the staged rows) enter in the epilogue only.  K <= 512. */
+int sc_decode_linear_lnstats(const void* x, long long ldx, int M, int K, const void* w_scaled, long long ldw, int N, const float* colsum,
+                             const float* shift, float ln_eps, int act, const void* residual, long long ldr, void* y, long long ldy,
+                             hipStream_t stream);
 
 /* Fused attention for any head size that is a multiple of 8 up to 256 (csrc/attention_dh.hip): the reference's attention is head-size
  * agnostic (speechain/module/transformer/attention.py:53-65,88-106,131); FastSpeech2 runs 2 heads of 192
@@ -384,6 +390,12 @@ int sc_attention_dh_bwd(const void* Q, const void* K, const void* V, const void*
  *   this step's [q | k | v]; cache (N, Tmax, 2 d) [k | v]: slot (n, pos) is written, slots (table[n][t], t), t < pos, are read;
  *   out (N, d), row stride ldo: softmax(scale q K^T) V per head (speechain/module/transformer/attention.py:88-106 on one query row). */
 int sc_beam_table_update(const int* table_in, int* table_out, const long long* beam_idx, int N, int Tmax, int pos, hipStream_t stream);
+/* sc_beam_table_update plus the decoder input rows of the step in the same launch: x[n] = round(emb[tokens[n]] * emb_scale) * xscale +
+ * pe * alpha (speechain/module/prenet/embed.py:40-47 lookup and scaling, the cast to the compute type `dtype`, transformer/pos_enc.py:155-163
+ * for the one position `pos`: pe is that position's row of the encoding table, alpha the learnt scale or null). */
+int sc_decode_embed_step(int dtype, const float* emb, const long long* tokens, float emb_scale, const float* pe, const float* alpha,
+                         float xscale, void* x, const int* table_in, int* table_out, const long long* beam_idx, int N, int d, int V, int Tmax,
+                         int pos, hipStream_t stream);
 int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache, const int* table, void* out, long long ldo, int N, int H,
                         int Tmax, int pos, float scale, hipStream_t stream);
 
@@ -395,7 +407,9 @@ int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void* cache
  *     logaddexp(r_prev[.][0], r_prev[.][1]) is the row's <eos> score (:151-155); psi(., blank) = -1e20 (:158).  T <= 8192 (the rows' phi / r_sum live in LDS:
  *     2 T floats per row, up to 8 rows of a sentence per workgroup).
  *   sc_ctc_prefix_state: r_new (T, 2, N), the forward variables of the surviving candidates -- new row n = prefix of row beam_idx[n]
- *     extended by tokens[n] -- recomputed for those N pairs (the reference gathers them out of a (T, 2, N, V) tensor, :162-196). */
+ *     extended by tokens[n] -- recomputed for those N pairs (the reference gathers them out of a (T, 2, N, V) tensor, :162-196).  With
+ *     psi_prev (N, V) and psi_sel (N) the launch also gathers psi_sel[n] = psi_prev[beam_idx[n]][tokens[n]], the score the row was chosen
+ *     with (:63; both NULL: not wanted). */
 int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_frame, const float* r_prev, const long long* last, float* psi,
                          int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream);
 /* The same scores with the exponential factorised (exp(phi + x) = exp(phi - a) * exp(x - bmax)): E (B, T, V) = exp(x - bmax) and bmax (B, V) =
@@ -404,7 +418,7 @@ int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_fra
 int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float* bmax, const int* enc_lens, const int* eos_frame, const float* r_prev,
                               const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank, int eos, hipStream_t stream);
 int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
-                        const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream);
+                        const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, const float* psi_prev, float* psi_sel, hipStream_t stream);
 
 /* Row-wise top-K of a (R, L) f32 matrix, row stride ld: vals / idx (R, K) in descending order, ties by the lower index; K <= 64.
  * The candidate selection of a beam-search step (speechain/infer_func/beam_search.py:419-421: torch.topk over (batch, beam * vocab)). */

@@ -60,6 +60,31 @@ __global__ __launch_bounds__(256) void beam_table_kernel(const int* tin, int* to
   if (lane == 0) tout[(long long)n * Tmax + pos] = n;
 }
 
+// The head of a decoding step in one launch (one wave per hypothesis row): the ancestry table as beam_table_kernel writes it, and the row's
+// decoder input x[n] = round_T(emb[token[n]] * emb_scale) * xscale + pe * alpha -- nn.Embedding lookup (prenet/embed.py:40-47), the cast to
+// the compute type, and the positional encoding of position `pos` (transformer/pos_enc.py:155-163, evaluation mode).  As five launches
+// (lookup, scale, cast, encoding, table) on the branches of a replayed hipGraph these cost ~150 us of mostly idle device per position.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_embed_kernel(const float* emb, const long long* tokens, float emb_scale, const float* pe, const float* alpha,
+                                                           float xscale, T* x, const int* tin, int* tout, const long long* beam_idx, int N, int d,
+                                                           int Tmax, int pos) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const long long par = beam_idx ? beam_idx[n] : n;
+  for (int t = lane; t < pos; t += 64) tout[(long long)n * Tmax + t] = tin[par * Tmax + t];
+  if (lane == 0) tout[(long long)n * Tmax + pos] = n;
+  const float* erow = emb + tokens[n] * (long long)d;
+  const float a = alpha ? *alpha : 1.f;
+  for (int k = lane; k < d; k += 64) {
+    float e = erow[k] * emb_scale;
+    if (sizeof(T) == 2) e = sc_bf16_to_f32(sc_f32_to_bf16(e));
+    const float v = e * xscale + pe[k] * a;
+    if (sizeof(T) == 2) ((unsigned short*)x)[(long long)n * d + k] = sc_f32_to_bf16(v);
+    else ((float*)x)[(long long)n * d + k] = v;
+  }
+}
+
 // 16 bytes of a row as EPL floats
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
@@ -194,6 +219,25 @@ SC_API int sc_beam_table_update(const int* table_in, int* table_out, const long 
   SC_CHECK_ARG(N >= 1 && Tmax >= 1 && pos >= 0 && pos < Tmax, "sc_beam_table_update: bad sizes N=%d Tmax=%d pos=%d", N, Tmax, pos);
   hipLaunchKernelGGL(beam_table_kernel, dim3(sc_cdiv(N, 4)), dim3(256), 0, stream, table_in, table_out, beam_idx, N, Tmax, pos);
   SC_LAUNCH_CHECK("beam_table_kernel");
+  return SC_OK;
+}
+
+// sc_beam_table_update plus the decoder input rows of the step (see decode_embed_kernel): emb (V, d) f32 embedding table, tokens (N) the
+// newest token of every row, pe (d) the positional-encoding row of `pos`, alpha its learnt scale (device scalar) or null, x (N, d) of `dtype`.
+SC_API int sc_decode_embed_step(int dtype, const float* emb, const long long* tokens, float emb_scale, const float* pe, const float* alpha,
+                                float xscale, void* x, const int* table_in, int* table_out, const long long* beam_idx, int N, int d, int V, int Tmax,
+                                int pos, hipStream_t stream) {
+  SC_CHECK_ARG(emb && tokens && pe && x && table_out && (table_in || pos == 0), "sc_decode_embed_step: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_decode_embed_step: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(table_in != table_out, "sc_decode_embed_step: the tables must be two buffers");
+  SC_CHECK_ARG(N >= 1 && d >= 1 && V >= 1 && Tmax >= 1 && pos >= 0 && pos < Tmax, "sc_decode_embed_step: bad sizes N=%d d=%d Tmax=%d pos=%d", N, d, Tmax, pos);
+  if (dtype == 0)
+    hipLaunchKernelGGL(decode_embed_kernel<float>, dim3(sc_cdiv(N, 4)), dim3(256), 0, stream, emb, tokens, emb_scale, pe, alpha, xscale, (float*)x, table_in,
+                       table_out, beam_idx, N, d, Tmax, pos);
+  else
+    hipLaunchKernelGGL(decode_embed_kernel<unsigned short>, dim3(sc_cdiv(N, 4)), dim3(256), 0, stream, emb, tokens, emb_scale, pe, alpha, xscale,
+                       (unsigned short*)x, table_in, table_out, beam_idx, N, d, Tmax, pos);
+  SC_LAUNCH_CHECK("decode_embed_kernel");
   return SC_OK;
 }
 
@@ -443,7 +487,7 @@ __device__ __forceinline__ void la_wave_scan(const float* a, const float* b, flo
 // wave scans replace the T sequential steps (measured: 282 us per launch with one lane walking the frames).
 __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const int* enc_lens, const float* r_prev, const long long* last,
                                                        const long long* beam_idx, const long long* tokens, float* r_new, int N, int T, int V,
-                                                       int beam, int plen, int blank) {
+                                                       int beam, int plen, int blank, const float* psi_prev, float* psi_sel) {
   extern __shared__ float s_st[];  // [4 waves][4][T]: a (x label), b (x label + phi), then r^n; x blank
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + w;
@@ -454,6 +498,7 @@ __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const in
   float* xb = s_st + (w * 4 + 3) * T;
   const int par = (int)beam_idx[n], b = par / beam;
   const long long c = tokens[n];
+  if (psi_sel && lane == 0) psi_sel[n] = psi_prev[(long long)par * V + c];  // the prefix score this row was chosen with (ctc_decoding.py:63)
   const int len = enc_lens[b];
   const long long lastc = plen > 0 ? last[par] : 0;
   const float* xc = x + (long long)b * T * V;
@@ -543,14 +588,16 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
 // r_new (T, 2, N): the forward variables of the surviving candidates, new row n = prefix of row beam_idx[n] extended by tokens[n]
 // (what ctc_decoding.py:162-196 gathers out of its (T, 2, N, V) tensor).
 SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
-                               const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, hipStream_t stream) {
+                               const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, const float* psi_prev,
+                               float* psi_sel, hipStream_t stream) {
   SC_CHECK_ARG(x && enc_lens && r_prev && beam_idx && tokens && r_new && (last || plen == 0), "sc_ctc_prefix_state: null pointer");
+  SC_CHECK_ARG((psi_prev == nullptr) == (psi_sel == nullptr), "sc_ctc_prefix_state: psi_prev and psi_sel come together");
   SC_CHECK_ARG(r_prev != r_new, "sc_ctc_prefix_state: r_prev and r_new must be two buffers");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && V >= 1 && plen >= 0 && blank >= 0 && blank < V, "sc_ctc_prefix_state: bad sizes");
   const size_t smem = (size_t)4 * 4 * T * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_ctc_prefix_state: T too large for the LDS rows (%d frames)", T);
   hipLaunchKernelGGL(ctc_state_kernel, dim3(sc_cdiv(B * beam, 4)), dim3(256), smem, stream, x, enc_lens, r_prev, last, beam_idx, tokens, r_new,
-                     B * beam, T, V, beam, plen, blank);
+                     B * beam, T, V, beam, plen, blank, psi_prev, psi_sel);
   SC_LAUNCH_CHECK("ctc_state_kernel");
   return SC_OK;
 }

@@ -15,6 +15,12 @@
 // products read the normalised rows.  Every column tile of a row block repeats that (16-157 times 32 KB of LDS traffic): nothing next to the
 // launch it replaces (19 LayerNorm launches per step).
 //
+// The cheaper form of the same fold (LNM = 2; what the decoder's steps use): LayerNorm is affine per row, so
+//   LN(x) W^T + b = rstd (x (gamma . W)^T - mean colsum) + (W beta + b),   colsum[n] = sum_k bf16(gamma[k] W[n][k]).
+// The product runs on the RAW rows against the pre-scaled weight (made once per weight version on the host side: functional.py), the waves
+// start multiplying as their own k-tiles land exactly as without a LayerNorm, and only the epilogue needs the row statistics: one pass
+// over the staged rows (8 lanes per row, two-pass variance) AFTER the product loop, no write-back, no gamma / beta on chip.
+//
 // LDS image of an operand's super-tile: 16 k-tiles of [32 rows][32 k] (64-byte rows; one LDS-DMA instruction = 16 rows), 16-byte chunk index
 // XOR-ed with (row >> 2) & 3 on the source side and in the read addresses, as in gemm_bf16_nt_dma_kernel.
 #include "sc_common.h"
@@ -33,6 +39,7 @@ struct DecArgs {
   const float* bias;         // (N) or null
   const float* gamma;        // LayerNorm weight / bias (K) or null: no LayerNorm
   const float* beta;
+  const float* colsum;       // LNM = 2: row sums of the pre-scaled weight (N); bias then holds W beta + b
   const unsigned short* res; // residual (M, N), leading dimension ldr, or null
   long long ldx, ldw, ldy, ldr;
   int M, N, K;
@@ -42,11 +49,20 @@ struct DecArgs {
 
 constexpr int KS = 512;  // super-tile depth: 16 k-tiles of 32
 
+// sum over each group of 8 consecutive lanes, in every lane of the group (DPP: two quad permutes and the half-row mirror)
+__device__ __forceinline__ float oct_sum(float v) {
+  v += sc_dpp<0xB1, 0xF>(0.f, v);
+  v += sc_dpp<0x4E, 0xF>(0.f, v);
+  v += sc_dpp<0x141, 0xF>(0.f, v);
+  return v;
+}
+
 // TR: the output tile is (32 TR) x (32 TR).  TR = 1 puts a workgroup on every CU for the narrow products (N = 512: 256 workgroups of 64 KB
 // each); TR = 2 (64 x 64, 128 KB of operands: K <= 512 only) halves the bytes per output for the wide ones (q|k|v, ffn-in, the token head),
 // where 32 x 32 tiles would re-read every row of x N / 32 times.
-template <bool LN, int TR>
+template <int LNM, int TR>
 __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void decode_linear_kernel(DecArgs p) {
+  constexpr bool LN = LNM == 1;  // in-place normalisation of the staged rows; LNM == 2: statistics for the epilogue only
   constexpr int TROWS = 32 * TR;         // rows of x / of w per workgroup
   constexpr int KTE = TROWS * 32;        // elements of one operand k-tile
   constexpr int OPER = 16 * KTE;         // elements of one operand's super-tile
@@ -113,9 +129,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void decode_linear_kernel(Dec
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += __uint_as_float(w4[j] << 16) + __uint_as_float(w4[j] & 0xFFFF0000u);
       }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
+      s = oct_sum(s);
       const float mean = s / (float)p.K;
       float q = 0.f;
 #pragma unroll
@@ -128,9 +142,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void decode_linear_kernel(Dec
             q = fmaf(d0, d0, fmaf(d1, d1, q));
           }
         }
-      q += __shfl_xor(q, 1, 64);
-      q += __shfl_xor(q, 2, 64);
-      q += __shfl_xor(q, 4, 64);
+      q = oct_sum(q);
       const float rstd = rsqrtf(q / (float)p.K + p.eps);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -196,6 +208,47 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void decode_linear_kernel(Dec
   //      4 consecutive columns each: bias, activation, residual, bf16 store ----
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  float* rowstat = gb;  // LNM == 2: [TROWS] mean, [TROWS] rstd (behind the operand stage)
+  if (LNM == 2) {
+    // every wave's k-tiles have landed (each waited for its own before multiplying them): the rows are complete
+    const int sub = lane & 7;
+    const int nch = p.K >> 3;
+    for (int rep = 0; rep < TR; ++rep) {
+      const int row = wid * 8 * TR + rep * 8 + (lane >> 3);
+      const int sw = (row >> 2) & 3;
+      uint4 raw[8];
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = sub + 8 * i;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (c < nch) raw[i] = *(const uint4*)(dsm + (c >> 2) * KTE + row * 32 + (((c & 3) ^ sw) << 3));
+        const unsigned w4[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += __uint_as_float(w4[j] << 16) + __uint_as_float(w4[j] & 0xFFFF0000u);
+      }
+      sm = oct_sum(sm);
+      const float mean = sm / (float)p.K;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (sub + 8 * i < nch) {
+          const unsigned w4[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d0 = __uint_as_float(w4[j] << 16) - mean, d1 = __uint_as_float(w4[j] & 0xFFFF0000u) - mean;
+            q = fmaf(d0, d0, fmaf(d1, d1, q));
+          }
+        }
+      q = oct_sum(q);
+      if (sub == 0) {
+        rowstat[row] = mean;
+        rowstat[TROWS + row] = rsqrtf(q / (float)p.K + p.eps);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (the partial sums below overwrite the rows)
+  }
   float* red = (float*)dsm;  // [4 waves][TROWS][RED_LD]
 #pragma unroll
   for (int i = 0; i < TR; ++i)
@@ -219,6 +272,12 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void decode_linear_kernel(Dec
         o[4 * q4] = v[0]; o[4 * q4 + 1] = v[1]; o[4 * q4 + 2] = v[2]; o[4 * q4 + 3] = v[3];
       }
       const int nv = min(CPT, p.N - n);
+      if (LNM == 2) {
+        const float mean = rowstat[row], rstd = rowstat[TROWS + row];
+#pragma unroll
+        for (int e = 0; e < CPT; ++e)
+          if (e < nv) o[e] = rstd * (o[e] - mean * p.colsum[n + e]);
+      }
 #pragma unroll
       for (int e = 0; e < CPT; ++e) {
         if (p.bias && e < nv) o[e] += p.bias[n + e];
@@ -274,8 +333,34 @@ SC_API int sc_decode_linear(const void* x, long long ldx, int M, int K, const vo
   const bool big = K <= KS && (force_tr ? force_tr == 2 : (long long)sc_cdiv(M, 64) * sc_cdiv(N, 64) >= 160);
   const int tr = big ? 2 : 1;
   const size_t smem = (size_t)(K > KS ? 2 : 1) * (size_t)tr * 2 * 16 * 32 * 32 * sizeof(unsigned short) + (ln_gamma ? 2 * 512 * sizeof(float) : 0);
-  const void* fn = ln_gamma ? (big ? (const void*)decode_linear_kernel<true, 2> : (const void*)decode_linear_kernel<true, 1>)
-                            : (big ? (const void*)decode_linear_kernel<false, 2> : (const void*)decode_linear_kernel<false, 1>);
+  const void* fn = ln_gamma ? (big ? (const void*)decode_linear_kernel<1, 2> : (const void*)decode_linear_kernel<1, 1>)
+                            : (big ? (const void*)decode_linear_kernel<0, 2> : (const void*)decode_linear_kernel<0, 1>);
+  SC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  void* kargs[] = {&a};
+  SC_HIP(hipLaunchKernel(fn, dim3(sc_cdiv(N, 32 * tr), sc_cdiv(M, 32 * tr)), dim3(256), kargs, smem, stream));
+  return SC_OK;
+}
+
+// act(LayerNorm(x) W^T + b) + residual from the RAW rows x and the pre-scaled weight (see the top of the file):
+//   w_scaled (N, K) = bf16(gamma[k] W[n][k]),  colsum (N) = sum_k w_scaled[n][k],  shift (N) = W beta + b.
+SC_API int sc_decode_linear_lnstats(const void* x, long long ldx, int M, int K, const void* w_scaled, long long ldw, int N, const float* colsum,
+                                    const float* shift, float ln_eps, int act, const void* residual, long long ldr, void* y, long long ldy,
+                                    hipStream_t stream) {
+  SC_CHECK_ARG(x && w_scaled && y && colsum && shift, "sc_decode_linear_lnstats: null pointer");
+  SC_CHECK_ARG(M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && K <= KS, "sc_decode_linear_lnstats: bad sizes M=%d N=%d K=%d (K a multiple of 32, <= %d)", M, N, K, KS);
+  SC_CHECK_ARG(ldx >= K && ldw >= K && ldy >= N && ldx % 8 == 0 && ldw % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)w_scaled % 16 == 0,
+               "sc_decode_linear_lnstats: rows of x and w must be 16-byte aligned");
+  SC_CHECK_ARG(residual == nullptr || ldr >= N, "sc_decode_linear_lnstats: residual rows shorter than N");
+  SC_CHECK_ARG(act >= 0 && act <= 2, "sc_decode_linear_lnstats: act %d (0 none, 1 ReLU, 2 GELU)", act);
+  SC_CHECK_ARG((long long)sc_cdiv(M, 32) <= 65535, "sc_decode_linear_lnstats: too many rows");
+  DecArgs a{};
+  a.X = (const unsigned short*)x; a.W = (const unsigned short*)w_scaled; a.Y = (unsigned short*)y; a.bias = shift; a.colsum = colsum;
+  a.res = (const unsigned short*)residual; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.act = act; a.eps = ln_eps;
+  static const int force_tr = [] { const char* e = getenv("SC_DECODE_TR"); return e ? atoi(e) : 0; }();
+  const bool big = force_tr ? force_tr == 2 : (long long)sc_cdiv(M, 64) * sc_cdiv(N, 64) >= 160;
+  const int tr = big ? 2 : 1;
+  const size_t smem = (size_t)tr * 2 * 16 * 32 * 32 * sizeof(unsigned short) + 2 * 64 * sizeof(float);
+  const void* fn = big ? (const void*)decode_linear_kernel<2, 2> : (const void*)decode_linear_kernel<2, 1>;
   SC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   void* kargs[] = {&a};
   SC_HIP(hipLaunchKernel(fn, dim3(sc_cdiv(N, 32 * tr), sc_cdiv(M, 32 * tr)), dim3(256), kargs, smem, stream));

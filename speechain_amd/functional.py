@@ -254,6 +254,37 @@ class _WeightCache:
             self._put(key, params, buf)
         return buf
 
+    def ln_folded(self, ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], ln: torch.nn.LayerNorm):
+        """(w_scaled bf16 (N, K), colsum f32 (N), shift f32 (N)) for `sc_decode_linear_lnstats`: LN(x) W^T + b = rstd (x w_scaled^T - mean colsum)
+        + shift with w_scaled = bf16(gamma . W), colsum = its row sums (of the ROUNDED weights: the subtraction then cancels exactly what the
+        product accumulated), shift = W beta + b.  Made once per version of the parameters, rebuilt in place (a captured decoding graph holds
+        the addresses); inference only."""
+        params = list(ws) + [b for b in bs if b is not None] + [ln.weight, ln.bias]
+        key = tuple(id(p) for p in params)
+        store = self.__dict__.setdefault("ln_store", {})
+        hit = store.get(key)
+        if hit is not None and not all(r() is p for r, p in zip(hit[2], params)):
+            hit = None
+        ver = self._ver(params)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            Wf = torch.cat([self._matrix(w).float() for w in ws])
+            Wp = (Wf * ln.weight.detach().float()[None, :]).to(torch.bfloat16)
+            colsum = Wp.float().sum(dim=1)
+            shift = Wf @ ln.bias.detach().float()
+            if any(b is not None for b in bs):
+                shift = shift + torch.cat([b.detach().float() if b is not None else torch.zeros(w.size(0), device=w.device) for w, b in zip(ws, bs)])
+            new = (Wp.contiguous(), colsum.contiguous(), shift.contiguous())
+            if hit is not None:
+                for dst, src in zip(hit[1], new):
+                    dst.copy_(src)
+                new = hit[1]
+        if len(store) > 1024:
+            store.clear()
+        store[key] = (ver, new, tuple(weakref.ref(p) for p in params))
+        return new
+
     def refresh(self):
         """Rebuilds EVERY cached copy of live parameters in place -- one launch for the bf16 matrices (plain, fused, transposed), one
         for the float32 ones and the concatenated bias vectors -- and marks them current.  Call once per training step after the
@@ -1937,7 +1968,28 @@ def beam_table_update(table_in: Optional[torch.Tensor], table_out: torch.Tensor,
     lib.call("sc_beam_table_update", _p(table_in), _p(table_out), _p(beam_idx), N, Tmax, int(pos), stream())
 
 
+def decode_embed_step(emb: torch.Tensor, tokens: torch.Tensor, emb_scale: float, pe_row: torch.Tensor, alpha: Optional[torch.Tensor], xscale: float,
+                      table_in: Optional[torch.Tensor], table_out: torch.Tensor, beam_idx: Optional[torch.Tensor], pos: int) -> torch.Tensor:
+    """`beam_table_update` and the decoder input of the step -- embedding lookup (x emb_scale), cast to the compute type, positional encoding of
+    position `pos` -- in one launch (sc_decode_embed_step).  emb (V, d) f32, tokens (N,) int64, pe_row (d,) f32; returns x (N, d)."""
+    require_gpu(emb, "decode_embed_step")
+    N, Tmax = table_out.shape
+    V, d = emb.shape
+    dt = compute_dtype()
+    assert emb.dtype == torch.float32 and emb.is_contiguous() and tokens.dtype == torch.long and tokens.numel() == N and tokens.is_contiguous()
+    assert pe_row.dtype == torch.float32 and pe_row.numel() == d and pe_row.is_contiguous() and dt in (torch.float32, torch.bfloat16)
+    x = torch.empty(N, d, dtype=dt, device=emb.device)
+    lib.call("sc_decode_embed_step", BF16 if dt == torch.bfloat16 else F32, _p(emb), _p(tokens), float(emb_scale), _p(pe_row),
+             _p(alpha.detach()) if alpha is not None else None, float(xscale), _p(x), _p(table_in), _p(table_out), _p(beam_idx), N, d, V, Tmax,
+             int(pos), stream())
+    return x
+
+
+_DECODE_EMBED = _os.environ.get("SC_DECODE_EMBED", "1") == "1"  # (A/B knob: 0 = lookup, cast, encoding and table as their own launches)
 _DECODE_LINEAR = _os.environ.get("SC_DECODE_LINEAR", "1") == "1"  # (A/B knob: 0 = LayerNorm launch + the general GEMM kernel)
+
+
+_DECODE_LN_STATS = _os.environ.get("SC_DECODE_LN_STATS", "1") == "1"  # (A/B knob: 0 = LayerNorm folded in place / as its own launch)
 
 
 def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]], ln: Optional[torch.nn.LayerNorm] = None,
@@ -1952,7 +2004,11 @@ def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Opti
     # 6.5 us, LayerNorm + q 6.5 vs 8.7) and the long contraction (ffn-out, K = 2048: 7.3 vs 13.4) win; the wide ones (q|k|v 12.5 vs 9.0,
     # ffn-in 14.3 vs 10.2, the 5000-wide head 39 vs 16) lose -- every column tile re-stages and re-normalises its rows -- and stay on the
     # LayerNorm launch + the general kernel.
-    wide = n_out > 1024 and K <= 512
+    # With the LayerNorm applied through its row statistics in the epilogue (sc_decode_linear_lnstats: the product reads the raw rows) the
+    # wide products behind a LayerNorm (q|k|v, ffn-in) lose their LayerNorm launch as well and take this kernel too.
+    # (not the 5000-wide token head: at that width the general kernel wins by more than the LayerNorm launch costs)
+    stats = ln is not None and K <= 512 and n_out <= 2048 and _DECODE_LN_STATS
+    wide = n_out > 1024 and K <= 512 and not stats
     ok = (_DECODE_LINEAR and not wide and x2.dtype == torch.bfloat16 and x2.is_cuda and K % 32 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
           and (ln is None or K <= 512) and (activation is None or activation in ("ReLU", "GELU")) and not torch.is_grad_enabled())
     if not ok:
@@ -1963,9 +2019,7 @@ def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Opti
             y = linear_act(x, ws[0], bs[0], activation)
             return y if residual is None else y + residual
         return linear(x, ws, bs, residual=residual)
-    W = weights.fused(ws, x2.dtype)
-    b = weights.vector(bs)
-    M, N = x2.size(0), W.size(0)
+    M, N = x2.size(0), n_out
     y = torch.empty(M, N, dtype=x2.dtype, device=x2.device)
     res2 = None
     if residual is not None:
@@ -1973,6 +2027,13 @@ def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Opti
         if res2.stride(1) != 1:
             res2 = res2.contiguous()
     act = 0 if activation is None else ACT[activation]
+    if stats:
+        Wp, colsum, shift = weights.ln_folded(ws, bs, ln)
+        lib.call("sc_decode_linear_lnstats", _p(x2), x2.stride(0), M, K, _p(Wp), Wp.stride(0), N, _p(colsum), _p(shift), float(ln.eps), act, _p(res2),
+                 res2.stride(0) if res2 is not None else 0, _p(y), N, stream())
+        return y.reshape(*x.shape[:-1], N)
+    W = weights.fused(ws, x2.dtype)
+    b = weights.vector(bs)
     lib.call("sc_decode_linear", _p(x2), x2.stride(0), M, K, _p(W), W.stride(0), N, _p(b), _p(ln.weight.detach()) if ln is not None else None,
              _p(ln.bias.detach()) if ln is not None else None, float(ln.eps) if ln is not None else 0.0, act, _p(res2),
              res2.stride(0) if res2 is not None else 0, _p(y), N, stream())
@@ -2028,14 +2089,15 @@ def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int
     return psi
 
 
-def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int, out=None) -> torch.Tensor:
+def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int, out=None, psi_prev=None, psi_sel=None) -> torch.Tensor:
     """Forward variables (T, 2, N) of the rows that continue row beam_idx[n] with tokens[n] (sc_ctc_prefix_state)."""
     B, T, V = x.shape
     if r_prev is None:
         r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
     r_new = out if out is not None else torch.empty(T, 2, B * beam, dtype=torch.float32, device=x.device)
+    # (psi_prev (N, V) / psi_sel (N): the same launch also gathers psi_sel[n] = psi_prev[beam_idx[n], tokens[n]], ctc_decoding.py:63)
     lib.call("sc_ctc_prefix_state", _p(x), _p(enc_lens), _p(r_prev.contiguous()), _p(last), _p(beam_idx.contiguous()), _p(tokens), _p(r_new),
-             B, beam, T, V, int(plen), int(blank), stream())
+             B, beam, T, V, int(plen), int(blank), _p(psi_prev), _p(psi_sel), stream())
     return r_new
 
 

@@ -118,6 +118,8 @@ class _HarnessDecoder:
     def forward_step(self, tokens, cache, beam_idx=None):
         m = self.m
         with torch.no_grad():
+            if isinstance(getattr(m.embed, "embed", None), torch.nn.Embedding):  # (the lookup joins the step's first launch)
+                return m.decoder.token_head_step(tokens, cache, beam_idx, m.postnet.linear, embedding=m.embed)
             emb = m.embed(tokens.unsqueeze(1)).squeeze(1)
             return m.decoder.token_head_step(emb, cache, beam_idx, m.postnet.linear)
 

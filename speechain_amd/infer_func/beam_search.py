@@ -140,8 +140,7 @@ class _Session:
                 with (side if side is not None else contextlib.nullcontext()):
                     if pos > 0:
                         Fn.ctc_prefix_state(self.x, self.enc_lens, self.r[pos & 1 ^ 1], self.prev_tokens, pos - 1, self.beam_idx, self.tokens, beam,
-                                            self.pad, out=self.r[pos & 1])
-                        self.psi_sel.copy_(self.psi[pos & 1 ^ 1][self.beam_idx, self.tokens])
+                                            self.pad, out=self.r[pos & 1], psi_prev=self.psi[pos & 1 ^ 1], psi_sel=self.psi_sel)
                     psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
                                                beam, self.pad, self.sos_eos, out=self.psi[pos & 1],
                                                factors=(self.E, self.bmax) if self.E is not None else None)

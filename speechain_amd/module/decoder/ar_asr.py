@@ -39,7 +39,11 @@ class ARASRDecoder(Module):
     def forward_step(self, tokens: torch.Tensor, cache, beam_idx: torch.Tensor = None) -> torch.Tensor:
         """tokens (N,) int64: the newest token of every hypothesis row; returns the (N, vocab) logits of the next one."""
         with torch.no_grad():
-            emb = self.embedding(tokens.unsqueeze(1)).squeeze(1)
             if hasattr(self.decoder, "token_head_step"):
+                fused = isinstance(getattr(self.embedding, "embed", None), torch.nn.Embedding)  # (EmbedPrenet: the lookup joins the step's first launch)
+                if fused:
+                    return self.decoder.token_head_step(tokens, cache, beam_idx, self.postnet.linear, embedding=self.embedding)
+                emb = self.embedding(tokens.unsqueeze(1)).squeeze(1)
                 return self.decoder.token_head_step(emb, cache, beam_idx, self.postnet.linear)
+            emb = self.embedding(tokens.unsqueeze(1)).squeeze(1)
             return self.postnet(self.decoder.forward_step(emb, cache, beam_idx))

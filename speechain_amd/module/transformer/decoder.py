@@ -7,6 +7,7 @@ Quirks kept: the enc-dec attention never scales by head (:76-78), the decoder ne
 layers (:271-285), ``emb_scale`` defaults to True (:187).  The causal mask is not materialised: the softmax kernel
 combines the (B,1,L) padding mask with ``k <= q``.
 """
+import math
 import os
 
 import torch
@@ -177,7 +178,8 @@ class TransformerDecoder(Module):
         self_kv = [torch.zeros(N, max_len, 2 * d, dtype=src.dtype, device=src.device) for _ in self.trfm_layers]
         return DecodeCache(self_kv, cross, src_mask.clone(), beam, max_len, src.device)
 
-    def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None, _skip_final_ln: bool = False) -> torch.Tensor:
+    def forward_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor = None, _skip_final_ln: bool = False,
+                     _embed=None) -> torch.Tensor:
         """tgt (N, d): the embedded token every hypothesis row feeds at position ``cache.pos``; ``beam_idx`` (N,) int64: the row each
         hypothesis continues (the selection of the previous step; None = unchanged order).  Returns the (N, d) decoder output of that
         position -- what ``forward`` gives at the last position of the prefix.  ``_skip_final_ln``: the caller folds the stack's final
@@ -187,8 +189,18 @@ class TransformerDecoder(Module):
             raise RuntimeError(f"speechain_amd: the decoding cache holds {cache.max_len} positions")
         with torch.no_grad():
             t_in, t_out = cache.tables[pos & 1 ^ 1], cache.tables[pos & 1]
-            Fn.beam_table_update(t_in if pos > 0 else None, t_out, beam_idx, pos)
-            x = self.posenc.forward_step(tgt, pos)
+            pe = self.posenc
+            if _embed is not None and Fn._DECODE_EMBED and not hasattr(pe, "emb_layernorm") and Fn.compute_dtype() in (torch.float32, torch.bfloat16):
+                # tgt holds TOKENS: lookup, cast, positional encoding and the ancestry table in one launch (_embed = (table, scale))
+                if pos >= pe.posenc.size(1):
+                    pe.update_posenc(pos + 1)
+                x = Fn.decode_embed_step(_embed[0], tgt, _embed[1], pe.posenc[0, pos], pe.alpha if hasattr(pe, "alpha") else None,
+                                         math.sqrt(pe.d_model) if pe.emb_scale else 1.0, t_in if pos > 0 else None, t_out, beam_idx, pos)
+            else:
+                if _embed is not None:
+                    tgt = _embed[2](tgt.unsqueeze(1)).squeeze(1)
+                Fn.beam_table_update(t_in if pos > 0 else None, t_out, beam_idx, pos)
+                x = pe.forward_step(tgt, pos)
             for layer, kv, ckv in zip(self.trfm_layers, cache.self_kv, cache.cross_kv):
                 x = layer.forward_step(x, kv, t_out, pos, ckv, cache.src_mask, cache.beam)
             if self.layernorm_first and not _skip_final_ln:
@@ -196,8 +208,15 @@ class TransformerDecoder(Module):
         cache.pos = pos + 1
         return x
 
-    def token_head_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor, head: nn.Linear) -> torch.Tensor:
-        """``head(forward_step(...))`` with the final LayerNorm of a pre-LN stack folded into the head's product (one launch)."""
-        x = self.forward_step(tgt, cache, beam_idx, _skip_final_ln=True)
+    def token_head_step(self, tgt: torch.Tensor, cache: DecodeCache, beam_idx: torch.Tensor, head: nn.Linear, embedding=None) -> torch.Tensor:
+        """``head(forward_step(...))`` with the final LayerNorm of a pre-LN stack folded into the head's product (one launch).  With
+        ``embedding`` (an ``EmbedPrenet``) ``tgt`` holds the rows' newest TOKENS and the lookup joins the step's first launch."""
+        emb = None
+        if embedding is not None:
+            w = embedding.embed.weight
+            emb = (w.detach(), math.sqrt(w.size(1)) if getattr(embedding, "scale", False) else 1.0, embedding)  # (prenet/embed.py:46: x sqrt(dim))
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                tgt, emb = embedding(tgt.unsqueeze(1)).squeeze(1), None
+        x = self.forward_step(tgt, cache, beam_idx, _skip_final_ln=True, _embed=emb)
         with torch.no_grad():
             return Fn.decode_linear(x, [head.weight], [head.bias], ln=self.layernorm if self.layernorm_first else None)
