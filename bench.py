@@ -458,9 +458,9 @@ class ASRTrainStepWorkload:
                         "sc_gemm/sc_gemm_splitk launch (the timed steps all replay hipGraphs; `value`/`ms_per_step` do not contain it); `kernel` is the single GEMM kernel with the largest summed time in that step, achieved = its "
                         "2*M*N*K*batch flops / its event time; the split-K entries of by_kernel time two launches (product + "
                         "splitk_reduce_kernel) in one interval and are therefore not eligible as `kernel`; traffic: "
-                        "HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_train_step_pmc_traffic.json: "
+                        "HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_train_step_pmc_traffic.json, or the newest earlier one: "
                         "FETCH_SIZE x 2 + WRITE_SIZE over eager steps, averaged over the mix of shapes the kernel serves); mfma_busy_pmc: its matrix-core busy "
-                        "fraction from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (profiles/r02_train_step_pmc_mfma.json)"}
+                        "fraction from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (profiles/r03_train_step_pmc_mfma.json, or the newest earlier one)"}
 
 
 # ---- BASELINE configs[4]: FastSpeech2 train step -----------------------------------------------------
@@ -777,7 +777,8 @@ def cpu_baseline_decode(seconds: float):
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
-    for name in ("r02_frontend_pmc_traffic.json", "r02_train_step_pmc_traffic.json", "r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
+    for name in ("r03_frontend_pmc_traffic.json", "r03_train_step_pmc_traffic.json", "r02_frontend_pmc_traffic.json", "r02_train_step_pmc_traffic.json",
+                 "r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
@@ -789,12 +790,14 @@ def pmc_traffic(kernel: str):
 
 def pmc_mfma_busy(kernel: str):
     """Matrix-core busy fraction of `kernel` from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (None when there is none)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_train_step_pmc_mfma.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel]["mfma_busy_frac"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r03_train_step_pmc_mfma.json", "r02_train_step_pmc_mfma.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                return json.load(f)[kernel]["mfma_busy_frac"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline_train(seconds: float, prenet_dims=(64, 64)):
@@ -1030,7 +1033,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(wl.dominant),
                     "kernel_ms": round(kms, 5), "algorithmic_bytes": wl.alg_bytes,
                     "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes "
-                                    "(profiles/r02_frontend_pmc_traffic.json); bench.py cannot run the profiler on itself"}
+                                    "(profiles/r03_frontend_pmc_traffic.json, or the newest earlier round's); bench.py cannot run the profiler on itself"}
         else:
             roof = wl.roofline()
         line = {

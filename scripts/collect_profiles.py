@@ -1,5 +1,5 @@
 """Copies the summaries written by scripts/run_profiles.sh from gpurun_out/prof/ into profiles/<round>_* and prints the figures DESIGN.md
-quotes.  Run in the build container after the gpurun call:   python scripts/collect_profiles.py r02"""
+quotes.  Run in the build container after the gpurun call:   python scripts/collect_profiles.py r03"""
 import collections
 import csv
 import glob
@@ -27,7 +27,7 @@ def traffic(prefix, keys, note):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(newest(G + f"{prefix}_{kind}/*/*counter_collection.csv"))):
             for key in keys:
-                if key in r["Kernel_Name"]:
+                if key.rstrip(">") in r["Kernel_Name"]:  # (a key names a kernel up to template parameters added after it was written)
                     agg[key].append(float(r["Counter_Value"]))
                     rows.append(dict(kernel=key, dispatch=r["Dispatch_Id"], counter=r["Counter_Name"], value=r["Counter_Value"],
                                      start_ns=r["Start_Timestamp"], end_ns=r["End_Timestamp"]))
@@ -42,7 +42,7 @@ def traffic(prefix, keys, note):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     for src, dst in (("bench_default.json", "train_step_bench_default"), ("bench_p512.json", "train_step_bench_prenet512"),
                      ("bench_frontend.json", "frontend_bench_default"), ("bench_tts.json", "tts_step_bench_default"),
                      ("train_bench.json", "train_step_bench_under_rocprof"), ("frontend_bench.json", "frontend_bench_under_rocprof"),
@@ -71,7 +71,7 @@ def main():
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(newest(G + "train_mfma/*/*counter_collection.csv"))):
             for key in TRAIN_KERNELS:
-                if key in r["Kernel_Name"]:
+                if key.rstrip(">") in r["Kernel_Name"]:
                     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         mf = {}
         for k, c in agg.items():
