@@ -268,22 +268,46 @@ class _WeightCache:
         ver = self._ver(params)
         if hit is not None and hit[0] == ver:
             return hit[1]
+        new = self._ln_build(ws, bs, ln.weight, ln.bias, hit[1] if hit is not None else None)
+        if len(store) > 1024:
+            store.clear()
+        none_ref = lambda: None
+        store[key] = (ver, new, tuple(weakref.ref(p) for p in params),
+                      (tuple(weakref.ref(w) for w in ws), tuple(weakref.ref(b) if b is not None else none_ref for b in bs)))
+        return new
+
+    def _ln_build(self, ws, bs, gamma, beta, into):
         with torch.no_grad():
             Wf = torch.cat([self._matrix(w).float() for w in ws])
-            Wp = (Wf * ln.weight.detach().float()[None, :]).to(torch.bfloat16)
+            Wp = (Wf * gamma.detach().float()[None, :]).to(torch.bfloat16)
             colsum = Wp.float().sum(dim=1)
-            shift = Wf @ ln.bias.detach().float()
+            shift = Wf @ beta.detach().float()
             if any(b is not None for b in bs):
                 shift = shift + torch.cat([b.detach().float() if b is not None else torch.zeros(w.size(0), device=w.device) for w, b in zip(ws, bs)])
             new = (Wp.contiguous(), colsum.contiguous(), shift.contiguous())
-            if hit is not None:
-                for dst, src in zip(hit[1], new):
+            if into is not None:
+                for dst, src in zip(into, new):
                     dst.copy_(src)
-                new = hit[1]
-        if len(store) > 1024:
-            store.clear()
-        store[key] = (ver, new, tuple(weakref.ref(p) for p in params))
+                new = into
         return new
+
+    def sync(self):
+        """Brings every cached copy whose parameters have changed since it was made up to date IN PLACE, without a lookup by the layers that
+        use it: for code that replays captured launches (the beam search's per-position hipGraphs hold the copies' addresses and never
+        run the host-side lookups again).  No launches when nothing changed."""
+        live = [(k, v) for k, v in self.store.items() if all(r() is not None for r in v[2])]
+        if any(v[0] != self._ver([r() for r in v[2]]) for _, v in live):
+            self.refresh()
+        for key, hit in list(self.__dict__.get("ln_store", {}).items()):
+            params = [r() for r in hit[2]]
+            if any(p is None for p in params):
+                del self.ln_store[key]
+                continue
+            ver = self._ver(params)
+            if hit[0] != ver:
+                ws, bs = [r() for r in hit[3][0]], [r() for r in hit[3][1]]
+                self._ln_build(ws, bs, params[-2], params[-1], hit[1])
+                self.ln_store[key] = (ver,) + hit[1:]
 
     def refresh(self):
         """Rebuilds EVERY cached copy of live parameters in place -- one launch for the bf16 matrices (plain, fused, transposed), one
@@ -340,6 +364,7 @@ class _WeightCache:
     def invalidate(self):
         """Drops every cached copy (buffers included: not for use between the capture and the replays of a hipGraph)."""
         self.store.clear()
+        self.__dict__.get("ln_store", {}).clear()
         self._desc = {}
 
 

@@ -113,6 +113,8 @@ class _Session:
 
     def begin(self, enc_feat, enc_feat_mask, scorer: Optional[CTCPrefixScorer]):
         self.calls += 1
+        if self.graphs:
+            Fn.weights.sync()  # (the replayed positions read cached weight copies by address: a parameter update since the capture must reach them)
         self.cache = self.fn.start_decoding(enc_feat, enc_feat_mask, self.beam, self.max_len, reuse=self.cache)
         self.tokens.fill_(self.sos_eos)
         self.scores.fill_(float("-inf"))

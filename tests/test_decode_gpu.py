@@ -287,6 +287,47 @@ def test_cached_and_prefix_beam_search_agree_at_recipe_width():
         assert torch.allclose(got["hypo_text_confid"], want["hypo_text_confid"], atol=1e-3)
 
 
+def test_replayed_decoding_follows_parameter_updates():
+    """The per-position hipGraphs of a decoding session read the cached bf16 weight copies by address and never run the layers' host-side
+    lookups again: after an in-place parameter update (a training step between two validation decodes) the replayed search must use the new
+    weights -- it has to equal the stateless calling convention (no cache, no graphs) on the updated model, and differ from the old result."""
+    from speechain_amd import functional as Fn
+    from speechain_amd.infer_func.beam_search import beam_searching
+    from speechain_amd.module.decoder.ar_asr import ARASRDecoder
+    from speechain_amd.utilbox.train_util import make_mask_from_len
+
+    torch.manual_seed(7)
+    V = 300
+    dec = ARASRDecoder(vocab_size=V, embedding=dict(type="prenet.embed.EmbedPrenet", conf=dict(embedding_dim=512)),
+                       decoder=dict(type="transformer.decoder.TransformerDecoder",
+                                    conf=dict(num_heads=8, num_layers=2, fdfwd_dim=2048, fdfwd_activation="GELU", emb_scale=False))).cuda().eval()
+    with torch.no_grad():
+        dec.postnet.linear.weight.mul_(3.0)
+    enc = torch.randn(2, 64, 512).cuda()
+    mask = make_mask_from_len(torch.tensor([64, 50]), max_len=64).cuda()
+    kw = dict(vocab_size=V, beam_size=4, min_f2t_ratio=4.0)
+    stateless = lambda enc_feat, enc_feat_mask, text, text_len: dec(enc_feat, enc_feat_mask, text, text_len)
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        for _ in range(3):  # eager, captured + replayed, replayed
+            before = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=dec, **kw)
+        with torch.no_grad():  # an "optimizer step": every matrix of the decoder stack and the LayerNorm in front of the products
+            for n, p in dec.named_parameters():
+                if p.dim() == 2 and "embed" not in n:
+                    p.add_(0.05 * torch.randn_like(p) * p.std())
+                elif n.endswith("layernorm.weight") or "norm" in n and n.endswith("weight"):
+                    p.mul_(1.1)
+        after = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=dec, **kw)  # replayed
+        want = beam_searching(enc_feat=enc, enc_feat_mask=mask, asr_decode_fn=stateless, **kw)
+        assert not torch.equal(after["hypo_text_confid"], before["hypo_text_confid"])  # (the update is large enough to move the scores)
+        assert torch.allclose(after["hypo_text_confid"], want["hypo_text_confid"], rtol=2e-2, atol=2e-2), (after["hypo_text_confid"], want["hypo_text_confid"],
+                                                                                                            before["hypo_text_confid"])
+        assert not torch.allclose(before["hypo_text_confid"], want["hypo_text_confid"], rtol=2e-2, atol=2e-2)
+    finally:
+        Fn.set_compute_dtype(None)
+        Fn.weights.invalidate()
+
+
 @pytest.mark.parametrize("plen", [0, 1, 3, 9])
 def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen):
     """sc_ctc_prefix_scores_fast (exp(phi + x) = exp(phi - a) exp(x - bmax), the second factor made once per batch) against the exact
