@@ -132,6 +132,19 @@ def prenet_conf(dims):
     return dict(conv_dims=list(dims), conv_kernel=3, conv_stride=2, conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=512)
 
 
+def syncbn_group():
+    """A communicator of their own for the BatchNorm statistics.  Their all-reduces are captured into the step's hipGraphs and run on the
+    main stream in graph order, identically on every rank; on the DEFAULT group they would share a communicator with the eager all-gather of
+    the next batch's normalisation statistics (head stream), and two collectives of one communicator that the ranks may start in different
+    orders are a deadlock.  (None -- the default group -- if the group cannot be made.)"""
+    import torch.distributed as dist
+    try:
+        return dist.new_group(backend="nccl")
+    except Exception as e:
+        print(f"bench: dist.new_group failed ({e}); BatchNorm statistics stay on the default process group", file=sys.stderr)
+        return None
+
+
 class ASRTrainStepWorkload:
     """BASELINE.json configs[2] driven from waveforms: frontend -> global mean/std normalisation -> SpecAugment -> Conv2dPrenet (row f2; channels
     from --prenet-dims) -> 12-layer encoder -> 6-layer decoder -> CTC + CE heads -> backward -> grad clip -> Adam (Noam), bf16 compute."""
@@ -165,7 +178,7 @@ class ASRTrainStepWorkload:
         if distributed and os.environ.get("BENCH_SYNCBN", "1") == "1":
             # speechain/runner.py:1856-1858 (`enable_syncbatchnorm`, default True): every BatchNorm of a DDP model normalises with the
             # statistics of the batches of ALL ranks -- the HIP prenet all-reduces its C-sized sums between its reduce and finish kernels
-            self.prenet = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.prenet)
+            self.prenet = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.prenet, process_group=syncbn_group())
         self.model = ASRTransformer(**ASR_MODEL).to(device).train()
         for m in (self.prenet, self.model):
             for p in m.parameters():
@@ -375,7 +388,14 @@ class ASRTrainStepWorkload:
         self._load_batch()
         graph = self.use_graph and not instrument and self.nstep > 3
         if graph and self.g_body is None:
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:  # (e.g. a runtime that refuses a collective inside a capture: keep the run, eagerly, and say so)
+                print(f"bench: capturing the step into hipGraphs failed ({type(e).__name__}: {e}); continuing with eager steps", file=sys.stderr)
+                self.use_graph, graph = False, False
+                self.g_body = self.g_tail = None
+                self.g_pieces, self.piece_buckets = [], []
+                torch.cuda.synchronize()
         if graph and self.segmented:
             for g, ready in zip(self.g_pieces, self.piece_buckets):
                 g.replay()
@@ -528,7 +548,7 @@ class TTSTrainStepWorkload:
         torch.manual_seed(0)
         self.model = TTSFastSpeech2(TTS_VOCAB, tts_recipe_conf(*TTS_DROPOUT)).to(device).train()
         if distributed and os.environ.get("BENCH_SYNCBN", "1") == "1":  # (the postnet's BatchNorm1d blocks: runner.py:1856-1858)
-            self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
+            self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model, process_group=syncbn_group())
         for p in self.model.parameters():
             if p.dim() > 1:
                 torch.nn.init.xavier_normal_(p)
@@ -593,12 +613,17 @@ class TTSTrainStepWorkload:
         if graph and self.g_body is None:
             self.reducer.wait()  # (collectives of the eager warm-up steps are complete before capture starts; see ASRTrainStepWorkload._capture)
             torch.cuda.synchronize()
-            self.g_body = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
-                self.loss = self._body()
-            self.g_tail = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
-                self.opt.step()
+            try:
+                self.g_body = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
+                    self.loss = self._body()
+                self.g_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
+                    self.opt.step()
+            except Exception as e:  # (see ASRTrainStepWorkload.step)
+                print(f"bench: capturing the step into hipGraphs failed ({type(e).__name__}: {e}); continuing with eager steps", file=sys.stderr)
+                self.use_graph, graph = False, False
+                self.g_body = self.g_tail = None
             torch.cuda.synchronize()
         if graph:
             self.g_body.replay()
@@ -1053,8 +1078,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "per_gpu_batch": BATCH, "samples_per_utt": TTS_SAMPLES if args.workload == "tts_train_step" else SAMPLES,
                        "sharding": (f"{world} independent per-GPU batches, no collective" if args.workload in ("frontend", "asr_decode") else
-                                    f"dp{world}: per-GPU batch 32; eager launches; the gradient all-reduce in 32 MB flat buckets is issued from "
-                                    "the per-parameter hooks on a communication stream (a single rank: none)" if args.workload == "tts_train_step" else
+                                    f"dp{world}: per-GPU batch 32; body hipGraph, then the gradient all-reduce in 32 MB flat buckets on a "
+                                    "communication stream, then the optimizer hipGraph (a single rank: no collective)" if args.workload == "tts_train_step" else
                                     f"dp{world}: per-GPU batch 32; one exchange per step, the RCCL gradient all-reduce in 32 MB flat "
                                     "buckets" + (" -- backward is replayed as five hipGraphs (cut at the encoder output, two encoder "
                                     "hidden states and the encoder input) and the buckets each piece completes are reduced on a "
@@ -1065,6 +1090,10 @@ def main():
                                     "normalisation statistics in the eager part of the step, as in the reference")},
             "roofline": roof,
         }
+        if args.workload in ("asr_train_step", "tts_train_step"):
+            line["config"]["hipgraphs"] = bool(getattr(wl, "use_graph", False) and wl.g_body is not None)  # (False: BENCH_NO_GRAPH=1 or a failed capture)
+            line["config"]["batchnorm"] = ("SyncBatchNorm statistics over all ranks (speechain/runner.py:1856-1858), (C,)-sized all-reduces on a "
+                                           "process group of their own" if (world > 1 and os.environ.get("BENCH_SYNCBN", "1") == "1") else "per-rank batch statistics (one rank)")
         if args.workload == "asr_train_step":
             line["config"]["prenet"] = PRENET_NOTE
             step_s = elapsed / args.steps
