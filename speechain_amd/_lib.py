@@ -12,7 +12,7 @@ from typing import Dict, List, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspeechain_amd.so")
+LIB_PATH = os.environ.get("SC_LIB_PATH") or os.path.join(_HERE, "lib", "libspeechain_amd.so")  # (SC_LIB_PATH: an instrumented build, scripts/*_probe.py)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "speechain_amd.h")
 
 _SCALARS = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float, "size_t": ctypes.c_size_t,

@@ -119,6 +119,12 @@ __device__ __forceinline__ bf16x8_t frag_value(const Frag& f) {
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// -DSC_WGRAD_TIMING (instrumented builds only, scripts/wgrad_probe.py): every workgroup records its physical XCC, its start and end on the
+// chip-wide 100 MHz clock and its K-tile count; read back with sc_wgrad_debug_read (not part of the ABI).
+#ifdef SC_WGRAD_TIMING
+__device__ long long sc_wgrad_probe[4096 * 4];
+#endif
+
 template <int WM, int WN, int MI>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_grouped_kernel(const Header* __restrict__ hdr, const int* __restrict__ tile0,
                                                                                           const Prob* __restrict__ probs) {
@@ -146,6 +152,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
   const int tm = lt / P.tiles_n, tn = lt - tm * P.tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
   const int nk = P.tokens / BK;
+#ifdef SC_WGRAD_TIMING
+  if (tid == 0 && blockIdx.x < 4096) {
+    unsigned xcc_;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+    sc_wgrad_probe[blockIdx.x * 4 + 0] = xcc_ & 15;
+    sc_wgrad_probe[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    sc_wgrad_probe[blockIdx.x * 4 + 3] = nk;
+  }
+#endif
 
   // per-lane source pointers of this wave's granules: granule index gi = wid + NW i covers sub-tile gi / 8 (A sub-tiles first),
   // token rows 4 (gi % 8) .. + 3; lane l fills LDS slot (row l >> 4, chunk l & 15) from source chunk (l & 15) ^ (4 (l >> 4)).
@@ -374,6 +389,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void wgrad_gr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xC07F);
   }
+#ifdef SC_WGRAD_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && blockIdx.x < 4096) sc_wgrad_probe[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int WM, int WN, int MI>
@@ -400,6 +419,13 @@ long long table_bytes(long long units) {
 }
 
 }  // namespace
+
+#ifdef SC_WGRAD_TIMING
+extern "C" __attribute__((visibility("default"))) int sc_wgrad_debug_read(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sc_wgrad_probe), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif
+
 
 static thread_local int g_last_tile = 0;
 // output tile edge (128 / 256) of the calling thread's last sc_wgrad_grouped call (measurement aid for bench.py)
