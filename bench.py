@@ -208,7 +208,12 @@ class ASRTrainStepWorkload:
         else:
             self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.9, 0.98), eps=1e-9, fused=True, capturable=True)
         torch.manual_seed(1234 + seed)
-        self.wave, self.lens, _ = synth_batch(seed, device)
+        self.wave, self.lens, lens_host = synth_batch(seed, device)
+        # (as in FrontendWorkload: the data loader knows the lengths on the host, so SpecAugment draws its indices on the host generator from the
+        # host-side frame counts -- no device-to-host reads and no one-workgroup randint launches on the prefetch stream; BENCH_DEVICE_DRAWS=1: as before)
+        self.host_lens = os.environ.get("BENCH_DEVICE_DRAWS", "0") != "1"
+        self.sa.host_draws = self.host_lens
+        self.flen_host = self.fe.speech2linear.frame_count(lens_host)
         self.text, self.text_len = synth_text(seed, device)
         self.feat = torch.zeros(BATCH, 1001, 80, device=device)      # static inputs of the captured region
         self.flen = torch.zeros(BATCH, dtype=torch.int64, device=device)
@@ -234,6 +239,9 @@ class ASRTrainStepWorkload:
         with torch.no_grad():  # frontend + SpecAugment stay eager: SpecAugment's index draws read the lengths on the host
             feat, flen = self.fe(self.wave, self.lens)
             feat, flen = self.norm(feat, flen, epoch=1)  # module/encoder/asr.py:111-115: between the frontend and SpecAugment
+            if self.host_lens:
+                out, _ = self.sa(feat, self.flen_host)
+                return out, flen
             return self.sa(feat, flen)
 
     def _load_batch(self):
