@@ -436,6 +436,11 @@ int sc_beam_pack(const float* vals, const long long* idx, const float* eos, cons
 int sc_beam_advance(const float* vals, const long long* idx, const float* eos, const float* other, int B, int K, int beam, int V,
                     int eos_token, double* pack, float* scores, long long* tokens, long long* prev_tokens, long long* beam_idx,
                     hipStream_t stream);
+/* sc_topk_merge over the B sentences (parts = beam) and sc_beam_advance in ONE launch: vals1 / idx1 (B * beam, K) are sc_topk_rows' results on
+ * the (B * beam, V) candidate scores; vals / idx (B, K) receive the merged selection too.  2 beam <= K <= 64, beam * K <= 1024. */
+int sc_beam_merge_advance(const float* vals1, const long long* idx1, int B, int beam, int K, int V, const float* eos, const float* other,
+                          int eos_token, float* vals, long long* idx, double* pack, float* scores, long long* tokens,
+                          long long* prev_tokens, long long* beam_idx, hipStream_t stream);
 int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, int K, int L, float* vals, long long* idx, hipStream_t stream);
 
 /* Candidate scores of a beam-search step (speechain/infer_func/beam_search.py:334-345,401-410) in one pass over the token head's logits:

@@ -2178,6 +2178,23 @@ def topk_groups(x: torch.Tensor, parts: int, k: int):
     return vals, idx
 
 
+def beam_select_advance(cand: torch.Tensor, beam: int, k: int, eos, other, eos_token: int, pack, scores, tokens, prev_tokens, beam_idx):
+    """The selection of a beam-search step from its (B * beam, V) candidate scores in two launches: every row's own top k (sc_topk_rows),
+    then merge per sentence + the step's record + the next rows (sc_beam_merge_advance).  Returns the merged (B, k) scores and indices.
+    Needs 2 * beam <= k <= 64 and beam * k <= 1024 (the caller falls back to `topk_groups` + `beam_advance` otherwise)."""
+    R, V = cand.shape
+    B = R // beam
+    v1, i1 = topk_rows(cand, k)
+    vals = torch.empty(B, k, dtype=torch.float32, device=cand.device)
+    idx = torch.empty(B, k, dtype=torch.long, device=cand.device)
+    assert pack.dtype == torch.float64 and pack.is_contiguous() and pack.shape == (B, 2 * k + (2 * beam if eos is not None else 0))
+    for t_, dt in ((scores, torch.float32), (tokens, torch.long), (prev_tokens, torch.long), (beam_idx, torch.long)):
+        assert t_.dtype == dt and t_.is_contiguous() and t_.numel() == B * beam
+    lib.call("sc_beam_merge_advance", _p(v1), _p(i1), B, int(beam), int(k), V, _p(eos), _p(other), int(eos_token), _p(vals), _p(idx), _p(pack),
+             _p(scores), _p(tokens), _p(prev_tokens), _p(beam_idx), stream())
+    return vals, idx
+
+
 def beam_candidates(logits: torch.Tensor, beam_score: torch.Tensor, temperature: float, psi=None, psi_prev=None, ctc_weight: float = 0.0,
                     blank: int = 0, eos: int = 0, want_eos_stats: bool = False):
     """(N, V) f32 candidate scores of a beam-search step from the token head's logits (sc_beam_candidates): length-V log-softmax at

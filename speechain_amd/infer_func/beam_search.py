@@ -155,6 +155,12 @@ class _Session:
                                                             w, self.pad, self.sos_eos, want_eos_stats=self.eos_filtering)
             # (two stages: every hypothesis row's own top 2 * beam, then the merge per sentence -- 512 workgroups over 5000 columns instead of
             #  32 over 80 000; same result as one selection over the sentence's beam * V candidates, ties included)
+            if self.ahead and beam > 1 and beam * 2 * beam <= 1024 and V >= 2 * beam:
+                # (merge, record and next rows in one launch behind the per-row top-k)
+                Fn.beam_select_advance(cand.view(B * beam, V), beam, 2 * beam, eos_score if self.eos_filtering else None,
+                                       other_max if self.eos_filtering else None, self.sos_eos, self.pack, self.scores, self.tokens, self.prev_tokens,
+                                       self.beam_idx)
+                return
             top_scores, top_ids = Fn.topk_groups(cand.view(B * beam, V), beam, 2 * beam) if 2 * beam <= 64 else \
                 torch.topk(cand.view(B, beam * V), 2 * beam, dim=1, largest=True, sorted=True)
             if self.ahead:
