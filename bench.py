@@ -132,6 +132,20 @@ def prenet_conf(dims):
     return dict(conv_dims=list(dims), conv_kernel=3, conv_stride=2, conv_batchnorm=True, conv_activation="LeakyReLU", lnr_dims=512)
 
 
+class no_gc:
+    """No cyclic garbage collection inside the block: a pass that frees graphs or device tensors while a stream is capturing calls into
+    the runtime in the middle of the capture, which aborts the process (seen in a test run)."""
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+        return False
+
+
 def syncbn_group():
     """A communicator of their own for the BatchNorm statistics.  Their all-reduces are captured into the step's hipGraphs and run on the
     main stream in graph order, identically on every rank; on the DEFAULT group they would share a communicator with the eager all-gather of
@@ -397,7 +411,8 @@ class ASRTrainStepWorkload:
         graph = self.use_graph and not instrument and self.nstep > 3
         if graph and self.g_body is None:
             try:
-                self._capture()
+                with no_gc():
+                    self._capture()
             except Exception as e:  # (e.g. a runtime that refuses a collective inside a capture: keep the run, eagerly, and say so)
                 print(f"bench: capturing the step into hipGraphs failed ({type(e).__name__}: {e}); continuing with eager steps", file=sys.stderr)
                 self.use_graph, graph = False, False
@@ -622,12 +637,13 @@ class TTSTrainStepWorkload:
             self.reducer.wait()  # (collectives of the eager warm-up steps are complete before capture starts; see ASRTrainStepWorkload._capture)
             torch.cuda.synchronize()
             try:
-                self.g_body = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
-                    self.loss = self._body()
-                self.g_tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
-                    self.opt.step()
+                with no_gc():
+                    self.g_body = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_body, capture_error_mode="thread_local"):
+                        self.loss = self._body()
+                    self.g_tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
+                        self.opt.step()
             except Exception as e:  # (see ASRTrainStepWorkload.step)
                 print(f"bench: capturing the step into hipGraphs failed ({type(e).__name__}: {e}); continuing with eager steps", file=sys.stderr)
                 self.use_graph, graph = False, False

@@ -451,6 +451,11 @@ int sc_topk_merge(const float* vals1, const long long* idx1, int G, int parts, i
 int sc_beam_candidates(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
                        float* cand, float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank, int eos,
                        hipStream_t stream);
+/* sc_beam_candidates + sc_topk_rows on its result in ONE launch, the (N, V) score matrix kept in LDS row by row and never written:
+ * vals / idx (N, K) = every row's K best candidate scores, descending, ties by the lower column.  V <= 12288, K <= 64. */
+int sc_beam_candidates_topk(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
+                            float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank, int eos,
+                            int K, float* vals, long long* idx, hipStream_t stream);
 
 /* Label-smoothed token cross entropy over (R, V) logits (speechain/criterion/cross_entropy.py:132-146):
  * row_loss[r] = -((1-eps) * lp[target] + eps/V * sum_v lp[v]) with lp = log_softmax(logits / temperature);

@@ -648,14 +648,14 @@ __device__ __forceinline__ void topk_find_bin(const unsigned* hist, int nbins, u
   }
 }
 
-__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long long ld, int L, int K, float* vals, long long* idx) {
+// (`row` may point into LDS -- the fused candidate kernel below stages its row there -- or into global memory: flat loads)
+__device__ __forceinline__ void topk_rows_body(const float* row, int L, int K, float* vals, long long* idx) {
   __shared__ unsigned hist[2048];
   __shared__ int sh_bin;
   __shared__ unsigned sh_above, sh_cnt, sh_eq_total, sh_eq_base[1025];
   __shared__ unsigned sel_key[64];
   __shared__ int sel_idx[64];
   const int tid = threadIdx.x;
-  const float* row = x + (long long)blockIdx.x * ld;
   unsigned prefix = 0, need = (unsigned)K;  // key bits fixed so far (from the top), elements still wanted among those matching the prefix
   // ---- three rounds: bits [31:21], [20:10], [9:0].  Scores cluster (same exponent): a lane adds a RUN of equal bins with one atomic ----
   const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
@@ -771,9 +771,13 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long lo
     const int id = sel_idx[tid];
     int rank = 0;
     for (int j = 0; j < K; ++j) rank += (sel_key[j] > k) || (sel_key[j] == k && sel_idx[j] < id);
-    vals[(long long)blockIdx.x * K + rank] = row[id];
-    idx[(long long)blockIdx.x * K + rank] = id;
+    vals[rank] = row[id];
+    idx[rank] = id;
   }
+}
+
+__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long long ld, int L, int K, float* vals, long long* idx) {
+  topk_rows_body(x + (long long)blockIdx.x * ld, L, K, vals + (long long)blockIdx.x * K, idx + (long long)blockIdx.x * K);
 }
 
 // Second stage of a two-stage top-K over G groups of `parts` rows each (see sc_topk_merge): candidate j of part p sits at column p K + j.
@@ -1043,10 +1047,89 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(const T* logits, l
   }
 }
 
+// beam_candidates_kernel and the row's own top K (topk_rows_body) in one launch: the candidate row lives in LDS only -- the (N, V) score
+// matrix (10 MB at N = 512, V = 5000) is never written, and the selection's four sweeps read LDS instead of L2.  1024 threads per row.
+template <typename T>
+__global__ __launch_bounds__(1024) void beam_candidates_topk_kernel(const T* logits, long long ld, const float* psi, const float* psi_prev,
+                                                                   const float* beam_score, float* eos_score, float* other_max, int V,
+                                                                   float inv_temp, float w, int blank, int eos, int K, float* vals,
+                                                                   long long* idx) {
+  extern __shared__ float candrow[];  // [V]
+  __shared__ float red[32];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const T* row = logits + (long long)n * ld;
+  float m = -INFINITY;
+  for (int v = tid; v < V; v += 1024) m = fmaxf(m, Elem<T>::ld(row + v) * inv_temp);
+  m = sc_wave_max(m);
+  if (lane == 0) red[wv] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+  float s = 0.f;
+  for (int v = tid; v < V; v += 1024) s += __expf(Elem<T>::ld(row + v) * inv_temp - m);
+  s = sc_wave_sum(s);
+  if (lane == 0) red[16 + wv] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot += red[16 + i];
+  const float lse = m + __logf(tot);
+  const float bs = beam_score[n];
+  const float pp = (psi && psi_prev) ? psi_prev[n] : 0.f;
+  float best_other = -INFINITY;
+  for (int v = tid; v < V; v += 1024) {
+    float t = Elem<T>::ld(row + v) * inv_temp - lse;
+    if (psi) {
+      if (v == blank) t = CTC_IMPOSSIBLE;
+      t = (1.f - w) * t + w * (psi[(long long)n * V + v] - pp);
+    }
+    candrow[v] = t + bs;
+    if (v == eos) {
+      if (eos_score) eos_score[n] = t;
+    } else {
+      best_other = fmaxf(best_other, t);
+    }
+  }
+  __syncthreads();
+  if (other_max) {
+    best_other = sc_wave_max(best_other);
+    if (lane == 0) red[wv] = best_other;
+    __syncthreads();
+    if (tid == 0) {
+      float o = red[0];
+      for (int i = 1; i < 16; ++i) o = fmaxf(o, red[i]);
+      other_max[n] = o;
+    }
+  }
+  topk_rows_body(candrow, V, K, vals + (long long)n * K, idx + (long long)n * K);
+}
+
 }  // namespace
 
 // cand (N, V) f32 as above.  dtype of logits: 0 = f32, 1 = bf16, row stride ld.  psi (N, V) / psi_prev (N) may be NULL (no CTC term / first
 // step); eos_score, other_max (N) may be NULL.
+// sc_beam_candidates followed by sc_topk_rows on its result, in one launch and without the (N, V) score matrix: vals / idx (N, K), every
+// row's K best candidate scores (descending, ties by the lower index) and their columns.  V * 4 bytes of LDS per workgroup: V <= 12288.
+SC_API int sc_beam_candidates_topk(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
+                                   float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank, int eos,
+                                   int K, float* vals, long long* idx, hipStream_t stream) {
+  SC_CHECK_ARG(logits && beam_score && vals && idx, "sc_beam_candidates_topk: null pointer");
+  SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_beam_candidates_topk: dtype must be 0 (f32) or 1 (bf16)");
+  SC_CHECK_ARG(N >= 1 && N <= 65535 && V >= 1 && V <= 12288 && ld >= V && temperature > 0.f && blank >= 0 && blank < V && eos >= 0 && eos < V &&
+                   K >= 1 && K <= 64 && K <= V,
+               "sc_beam_candidates_topk: bad sizes N=%d V=%d K=%d (V <= 12288, K <= 64)", N, V, K);
+  const size_t smem = (size_t)V * sizeof(float);
+  if (dtype == 0)
+    hipLaunchKernelGGL(beam_candidates_topk_kernel<float>, dim3(N), dim3(1024), smem, stream, (const float*)logits, ld, psi, psi_prev, beam_score,
+                       eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos, K, vals, idx);
+  else
+    hipLaunchKernelGGL(beam_candidates_topk_kernel<unsigned short>, dim3(N), dim3(1024), smem, stream, (const unsigned short*)logits, ld, psi,
+                       psi_prev, beam_score, eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos, K, vals, idx);
+  SC_LAUNCH_CHECK("beam_candidates_topk_kernel");
+  return SC_OK;
+}
+
 SC_API int sc_beam_candidates(int dtype, const void* logits, long long ld, const float* psi, const float* psi_prev, const float* beam_score,
                               float* cand, float* eos_score, float* other_max, int N, int V, float temperature, float ctc_weight, int blank,
                               int eos, hipStream_t stream) {

@@ -2195,6 +2195,30 @@ def beam_select_advance(cand: torch.Tensor, beam: int, k: int, eos, other, eos_t
     return vals, idx
 
 
+def beam_step_select(logits: torch.Tensor, temperature: float, psi, psi_prev, ctc_weight: float, blank: int, eos_token: int, want_eos_stats: bool,
+                     beam: int, k: int, pack, scores, tokens, prev_tokens, beam_idx):
+    """The tail of a beam-search step in TWO launches: candidate scores (log-softmax of the head's logits, CTC mixing, running scores) and
+    every row's own top k without the (N, V) score matrix (sc_beam_candidates_topk), then merge per sentence + the step's record + the
+    next rows (sc_beam_merge_advance).  `scores` is read (the rows' running scores) and then overwritten.  V <= 12288, 2 beam <= k <= 64,
+    beam * k <= 1024."""
+    require_gpu(logits, "beam_step_select")
+    N, V = logits.shape
+    B = N // beam
+    assert logits.stride(1) == 1 and scores.dtype == torch.float32
+    v1 = torch.empty(N, k, dtype=torch.float32, device=logits.device)
+    i1 = torch.empty(N, k, dtype=torch.long, device=logits.device)
+    es = torch.empty(N, dtype=torch.float32, device=logits.device) if want_eos_stats else None
+    om = torch.empty(N, dtype=torch.float32, device=logits.device) if want_eos_stats else None
+    lib.call("sc_beam_candidates_topk", dcode(logits), _p(logits), logits.stride(0), _p(psi), _p(psi_prev), _p(scores), _p(es), _p(om), N, V,
+             float(temperature), float(ctc_weight), int(blank), int(eos_token), int(k), _p(v1), _p(i1), stream())
+    vals = torch.empty(B, k, dtype=torch.float32, device=logits.device)
+    idx = torch.empty(B, k, dtype=torch.long, device=logits.device)
+    assert pack.dtype == torch.float64 and pack.is_contiguous() and pack.shape == (B, 2 * k + (2 * beam if want_eos_stats else 0))
+    lib.call("sc_beam_merge_advance", _p(v1), _p(i1), B, int(beam), int(k), V, _p(es), _p(om), int(eos_token), _p(vals), _p(idx), _p(pack),
+             _p(scores), _p(tokens), _p(prev_tokens), _p(beam_idx), stream())
+    return vals, idx
+
+
 def beam_candidates(logits: torch.Tensor, beam_score: torch.Tensor, temperature: float, psi=None, psi_prev=None, ctc_weight: float = 0.0,
                     blank: int = 0, eos: int = 0, want_eos_stats: bool = False):
     """(N, V) f32 candidate scores of a beam-search step from the token head's logits (sc_beam_candidates): length-V log-softmax at

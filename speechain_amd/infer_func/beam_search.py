@@ -21,6 +21,7 @@ What differs underneath:
     one hipGraph per position (``SC_DECODE_NO_GRAPH=1``: eager launches of the same code).
 """
 import contextlib
+import gc
 import os
 from typing import Callable, Dict, List, Optional
 
@@ -31,6 +32,7 @@ from speechain_amd import functional as Fn
 from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
 
 _CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "1") == "1"  # (A/B knob)
+_FUSED_TAIL = os.environ.get("SC_DECODE_FUSED_TAIL", "1") == "1"  # (A/B knob: 0 = candidate matrix in HBM, separate top-k launches)
 _CTC_PSI_FAST = os.environ.get("SC_CTC_PSI_FAST", "1") == "1"  # (A/B knob: 0 = one v_exp per (row, token, frame))
 
 eps = 1e-20
@@ -150,6 +152,12 @@ class _Session:
             logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
             if side is not None:
                 side.join()
+            fast_tail = self.ahead and beam > 1 and beam * 2 * beam <= 1024 and 2 * beam <= V <= 12288 and _FUSED_TAIL
+            if fast_tail:
+                # candidate scores + every row's top 2 * beam without the (N, V) matrix, then merge + record + next rows: two launches
+                Fn.beam_step_select(logits, self.temperature, psi, self.psi_sel if (self.ctc and pos > 0) else None, w, self.pad, self.sos_eos,
+                                    self.eos_filtering, beam, 2 * beam, self.pack, self.scores, self.tokens, self.prev_tokens, self.beam_idx)
+                return
             # log-softmax of the token head, CTC mixing (:334-345) and the rows' running scores in one kernel
             cand, eos_score, other_max = Fn.beam_candidates(logits, self.scores, self.temperature, psi, self.psi_sel if (self.ctc and pos > 0) else None,
                                                             w, self.pad, self.sos_eos, want_eos_stats=self.eos_filtering)
@@ -186,8 +194,16 @@ class _Session:
                     self.pool = torch.cuda.graph_pool_handle()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
-                    self._device_step(pos)
+                # (no cyclic collection while the stream is capturing: a pass that happens to free an older session's graphs or tensors
+                #  calls into the runtime in the middle of the capture, which aborts the process)
+                was_enabled = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                        self._device_step(pos)
+                finally:
+                    if was_enabled:
+                        gc.enable()
                 self.graphs[pos] = g
             g.replay()
         else:
