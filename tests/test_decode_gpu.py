@@ -287,6 +287,40 @@ def test_cached_and_prefix_beam_search_agree_at_recipe_width():
         assert torch.allclose(got["hypo_text_confid"], want["hypo_text_confid"], atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype,ctc,eos_stats", [(torch.float32, True, True), (torch.bfloat16, True, False), (torch.float32, False, False)])
+def test_fused_step_tail_equals_the_separate_launches(dtype, ctc, eos_stats):
+    """sc_beam_candidates_topk + sc_beam_merge_advance (candidate row in LDS, merge + record + next rows in one launch) against
+    sc_beam_candidates + sc_topk_rows + sc_topk_merge + sc_beam_advance on the same inputs: the same record and the same next rows."""
+    from speechain_amd import functional as Fn
+
+    B, beam, V, K = 5, 8, 3000, 16
+    N = B * beam
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(N, V, generator=g) * 3).to(dtype).cuda()
+    scores = torch.randn(N, generator=g).cuda()
+    psi = (torch.randn(N, V, generator=g) - 5).cuda() if ctc else None
+    psi_prev = torch.randn(N, generator=g).cuda() if ctc else None
+    eos = V - 1
+    logits[::3, eos] += 12.0  # <eos> among the best candidates of a third of the rows: the skipping rule is exercised
+    width = 2 * K + (2 * beam if eos_stats else 0)
+
+    def state():
+        return (torch.zeros(B, width, dtype=torch.float64, device="cuda"), scores.clone(), torch.arange(N, device="cuda"),
+                torch.zeros(N, dtype=torch.long, device="cuda"), torch.zeros(N, dtype=torch.long, device="cuda"))
+
+    pack_a, sc_a, tok_a, prev_a, par_a = state()
+    cand, es, om = Fn.beam_candidates(logits, sc_a, 1.3, psi, psi_prev, 0.2 if ctc else 0.0, 0, eos, want_eos_stats=eos_stats)
+    v, i = Fn.topk_groups(cand, beam, K)
+    Fn.beam_advance(v, i, es if eos_stats else None, om if eos_stats else None, beam, V, eos, pack_a, sc_a, tok_a, prev_a, par_a)
+    pack_b, sc_b, tok_b, prev_b, par_b = state()
+    v2, i2 = Fn.beam_step_select(logits, 1.3, psi, psi_prev, 0.2 if ctc else 0.0, 0, eos, eos_stats, beam, K, pack_b, sc_b, tok_b, prev_b, par_b)
+    torch.cuda.synchronize()
+    assert torch.equal(i2, i) and torch.allclose(v2, v, atol=2e-5, rtol=1e-6)
+    assert torch.equal(tok_b, tok_a) and torch.equal(par_b, par_a) and torch.equal(prev_b, prev_a) and torch.allclose(sc_b, sc_a, atol=2e-5, rtol=1e-6)
+    assert torch.allclose(pack_b, pack_a, atol=2e-5, rtol=1e-6)
+    assert int((tok_b == eos).sum()) == 0  # no row continues with <sos/eos>
+
+
 def test_replayed_decoding_follows_parameter_updates():
     """The per-position hipGraphs of a decoding session read the cached bf16 weight copies by address and never run the layers' host-side
     lookups again: after an in-place parameter update (a training step between two validation decodes) the replayed search must use the new
