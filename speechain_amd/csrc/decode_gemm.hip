@@ -327,10 +327,12 @@ SC_API int sc_decode_linear(const void* x, long long ldx, int M, int K, const vo
   DecArgs a{};
   a.X = (const unsigned short*)x; a.W = (const unsigned short*)w; a.Y = (unsigned short*)y; a.bias = bias; a.gamma = ln_gamma; a.beta = ln_beta;
   a.res = (const unsigned short*)residual; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.act = act; a.eps = ln_eps;
-  // 64 x 64 tiles when the contraction fits one stage and they still give most CUs a workgroup (the wide products); else 32 x 32.
+  // 32 x 32 tiles (SC_DECODE_TR=2: 64 x 64 when the contraction fits one stage).
   // LDS: one stage (64 KB x TR) when the whole contraction fits it, else two; + gamma | beta for the folded LayerNorm
   static const int force_tr = [] { const char* e = getenv("SC_DECODE_TR"); return e ? atoi(e) : 0; }();  // (A/B knob: 1 / 2 force the tile size)
-  const bool big = K <= KS && (force_tr ? force_tr == 2 : (long long)sc_cdiv(M, 64) * sc_cdiv(N, 64) >= 160);
+  // (64 x 64 tiles only on request: launched back to back the two tile sizes tie on the wide products, inside a decoding step -- every launch
+  //  behind a different kernel, weights cold -- the 32 x 32 tiles, two workgroups per CU, win: 60.7 -> 58.7 ms per batch)
+  const bool big = K <= KS && force_tr == 2;
   const int tr = big ? 2 : 1;
   const size_t smem = (size_t)(K > KS ? 2 : 1) * (size_t)tr * 2 * 16 * 32 * 32 * sizeof(unsigned short) + (ln_gamma ? 2 * 512 * sizeof(float) : 0);
   const void* fn = ln_gamma ? (big ? (const void*)decode_linear_kernel<1, 2> : (const void*)decode_linear_kernel<1, 1>)
@@ -357,7 +359,7 @@ SC_API int sc_decode_linear_lnstats(const void* x, long long ldx, int M, int K, 
   a.X = (const unsigned short*)x; a.W = (const unsigned short*)w_scaled; a.Y = (unsigned short*)y; a.bias = shift; a.colsum = colsum;
   a.res = (const unsigned short*)residual; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr; a.M = M; a.N = N; a.K = K; a.act = act; a.eps = ln_eps;
   static const int force_tr = [] { const char* e = getenv("SC_DECODE_TR"); return e ? atoi(e) : 0; }();
-  const bool big = force_tr ? force_tr == 2 : (long long)sc_cdiv(M, 64) * sc_cdiv(N, 64) >= 160;
+  const bool big = force_tr == 2;  // (see sc_decode_linear)
   const int tr = big ? 2 : 1;
   const size_t smem = (size_t)tr * 2 * 16 * 32 * 32 * sizeof(unsigned short) + 2 * 64 * sizeof(float);
   const void* fn = big ? (const void*)decode_linear_kernel<2, 2> : (const void*)decode_linear_kernel<2, 1>;
