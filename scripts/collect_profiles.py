@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out", "prof") + "/", os.path.join(ROOT, "profiles") + "/"
 
-TRAIN_KERNELS = ("gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>", "gemm_bf16_nt_dma_kernel<2, 2, 2, 2, false>", "gemm_bf16_nt_dma_kernel<2, 4, 4, 0, false>", "gemm_bf16_nt_dma_kernel<2, 2, 1, 2, false>",
+TRAIN_KERNELS = ("gemm_bf16_nt_dma_kernel<4, 2, 1, 0, false>", "gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>", "gemm_bf16_nt_dma_kernel<2, 2, 2, 2, false>", "gemm_bf16_nt_dma_kernel<2, 4, 4, 0, false>", "gemm_bf16_nt_dma_kernel<2, 2, 1, 2, false>",
                  "gemm_bf16_nt_dma_kernel<2, 1, 1, 1, false>", "wgrad_grouped_kernel<2, 4, 4>", "gemm_bf16_kernel<true, true>", "attn_fwd_stream_kernel",
                  "attn_bwd_kl_kernel<8, true>", "attn_bwd_kl_kernel<4, true>", "adam_step_kernel", "grad_sumsq_kernel", "cast_weights_kernel", "layernorm_bwd_vec_kernel", "layernorm_fwd_vec_kernel")
 

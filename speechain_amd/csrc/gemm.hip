@@ -1531,6 +1531,8 @@ static const char* const kGemmKernelNames[] = {
     "wgrad_grouped_kernel<2, 4, 4>",
     "wgrad_grouped_kernel<2, 2, 2>",
     "gemm_bf16_nt_dma_kernel<4, 2, 1, 2, false>",
+    "gemm_bf16_nt_dma_kernel<4, 2, 1, 0, false>",
+    "gemm_bf16_nt_dma_kernel<4, 2, 1, 1, false>",
 };
 SC_API int sc_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 // Experiment switches for A/B runs inside ONE process (scripts/ab_gemm_exp.py); not part of the ABI.  bit 0: launches of at most 256
@@ -1595,7 +1597,10 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // epilogue (FFN1 bias+GELU+dropout, act' dgrad) so that a second workgroup per CU covers the epilogue: 56.4 -> 61.7 us.]
       const long long t128 = (long long)sc_cdiv(M, 128) * sc_cdiv(N, 128) * nb;
       // (N <= 128, e.g. the 64-channel prenet convolution: a 256-wide tile would be three quarters empty)
-      static const long long bigmin = [] { const char* e = getenv("SC_GEMM_BIG_MIN"); return e ? atoll(e) : 200LL; }();  // (A/B knob; 7968 x 1536 x 512, 192 tiles of 256 x 256: 27.4 us, as 756 tiles of 128 x 128: 26.3 us)
+      static const long long bigmin = [] { const char* e = getenv("SC_GEMM_BIG_MIN"); return e ? atoll(e) : 700LL; }();  // (A/B knob; 7968 x 1536 x 512, 192 tiles of 256 x 256: 27.4 us, as 756 tiles of 128 x 128: 26.3 us.
+      // Round 3, measured inside the train step (three alternating runs per setting, one box): with the 256-tile (7968 x 2048) and 640-tile (7968 x 5000) products
+      // on the 8-wave 128 x 128 kernel as well and that kernel unpipelined (SC_GEMM_W8=1) the step is 0.8 % faster than with 200 / pipelined (8.17 vs 8.24 ms),
+      // neutral on a second box; the conv products of the [512,512] prenet (1250 tiles) stay on 256 x 256, which they prefer.)
       // (a batched product whose M is far from a multiple of 256 -- the per-utterance products of the im2col-free Conv1d: T = 640 frames
       //  would fill 3 row tiles of 256 to 83 %, T = 128 tokens one to 50 % -- takes 128-row tiles when those waste less)
       const bool ragged256 = (long long)sc_cdiv(M, 256) * 256 * 100 > (long long)sc_cdiv(M, 128) * 128 * 108;
@@ -1613,10 +1618,12 @@ SC_API int sc_gemm(int dtype, int ta, int tb, const void* A, const void* B, void
       // K = 512 10.5 -> 9.9 us, K = 1024 15.2 -> 14.4, K = 2048 25.5 -> 25.2, K = 96 7.1 -> 6.4, K = 2048 + bias + residual 28.1 -> 26.0;
       // step A/B (alternating, 60 steps): 9.17 / 9.17 ms without, 8.94 / 9.01 ms with.  SC_GEMM_W8=0 switches it off, SC_GEMM_W8_MAX=<tiles>
       // moves the threshold.
-      static const int w8 = [] { const char* e = getenv("SC_GEMM_W8"); return e ? atoi(e) : 3; }();
+      // Round 3: default 1, the unpipelined loop (was 3, fragments pipelined by whole tiles).  Launched back to back the pipelined form is 3-6 % faster; inside
+      // the step -- every launch behind a different kernel, instructions and first tiles cold -- the short loop wins (see SC_GEMM_BIG_MIN above and DESIGN 6r3).
+      static const int w8 = [] { const char* e = getenv("SC_GEMM_W8"); return e ? atoi(e) : 1; }();
       static const long long w8max = [] { const char* e = getenv("SC_GEMM_W8_MAX"); return e ? atoll(e) : (1LL << 60); }();
       if (w8 && t128 <= w8max && a.K % BK16 == 0) {
-        g_last_gemm_kernel = 15;
+        g_last_gemm_kernel = w8 == 1 ? 16 : w8 == 2 ? 17 : 15;
         if (w8 == 1) return launch_dma_pf<4, 2, 1, 0>(a, nb, stream);
         if (w8 == 2) return launch_dma_pf<4, 2, 1, 1>(a, nb, stream);
         if (g_gemm_exp & 64) return launch_dma_pf<4, 2, 1, 2, false, false, 8>(a, nb, stream);  // (experiment 64: eight stages in the ring)

@@ -2014,6 +2014,7 @@ _DECODE_EMBED = _os.environ.get("SC_DECODE_EMBED", "1") == "1"  # (A/B knob: 0 =
 _DECODE_LINEAR = _os.environ.get("SC_DECODE_LINEAR", "1") == "1"  # (A/B knob: 0 = LayerNorm launch + the general GEMM kernel)
 
 
+_DECODE_STATS_MAXN = int(_os.environ.get("SC_DECODE_STATS_MAXN", "2048"))  # (A/B knob: widest product that takes sc_decode_linear_lnstats)
 _DECODE_LN_STATS = _os.environ.get("SC_DECODE_LN_STATS", "1") == "1"  # (A/B knob: 0 = LayerNorm folded in place / as its own launch)
 
 
@@ -2032,7 +2033,7 @@ def decode_linear(x: torch.Tensor, ws: Sequence[torch.Tensor], bs: Sequence[Opti
     # With the LayerNorm applied through its row statistics in the epilogue (sc_decode_linear_lnstats: the product reads the raw rows) the
     # wide products behind a LayerNorm (q|k|v, ffn-in) lose their LayerNorm launch as well and take this kernel too.
     # (not the 5000-wide token head: at that width the general kernel wins by more than the LayerNorm launch costs)
-    stats = ln is not None and K <= 512 and n_out <= 2048 and _DECODE_LN_STATS
+    stats = ln is not None and K <= 512 and n_out <= _DECODE_STATS_MAXN and _DECODE_LN_STATS
     wide = n_out > 1024 and K <= 512 and not stats
     ok = (_DECODE_LINEAR and not wide and x2.dtype == torch.bfloat16 and x2.is_cuda and K % 32 == 0 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
           and (ln is None or K <= 512) and (activation is None or activation in ("ReLU", "GELU")) and not torch.is_grad_enabled())
