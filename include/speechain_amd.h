@@ -79,6 +79,20 @@ int sc_frontend_spec_finish(const float* spec, const long long* wave_len, int B,
                             const int* band_lo, const int* band_hi, int n_mels, int mag_spec, float clamp, int logging, float log_div,
                             float* out_feat, float* out_energy, float* out_linear, float lin_clamp, int lin_logging, float lin_log_div,
                             long long* feat_len, int T, hipStream_t stream);
+/* The wide transform in radix-4 form (n_fft a multiple of 4; a quarter of the product's flops): X[k] = sum_r e^{-2 pi i r k / n_fft}
+ * Y_r[k mod Q], Y_r the Q = n_fft / 4-point transforms of the four decimated, windowed sequences x[4 m + r].
+ *   sc_frontend_frames4: frames4 (4 B T, Q), row 4 f + r = window[4 m + r] x sample(4 m + r) of frame f (window: n_fft floats, zero-padded
+ *     around win_length as torch.stft pads it);
+ *   sc_gemm (f32): spec4 (4 B T, 32 * sc_frontend_num_tiles(Q)) = frames4 x the UNWINDOWED Q-point basis (sc_frontend_basis_init with a
+ *     window of ones, win_length = n_fft = Q);
+ *   sc_frontend_spec_finish4: the twiddled sum (twiddle (4, n_fft / 2 + 1, 2) f64 = cos, sin of 2 pi r k / n_fft; the sum runs in double), then as
+ *     sc_frontend_spec_finish. */
+int sc_frontend_frames4(const float* wave, const long long* wave_len, int B, int T_w, long long wave_stride, int use_preemph,
+                        float preemph, int n_fft, int hop, int center, int T, const float* window, float* frames4, hipStream_t stream);
+int sc_frontend_spec_finish4(const float* spec4, const double* twiddle, const long long* wave_len, int B, int T_w, int n_fft, int hop,
+                             int center, const float* melw, const int* band_lo, const int* band_hi, int n_mels, int mag_spec,
+                             float clamp, int logging, float log_div, float* out_feat, float* out_energy, float* out_linear,
+                             float lin_clamp, int lin_logging, float lin_log_div, long long* feat_len, int T, hipStream_t stream);
 
 /* ---- Griffin-Lim waveform recovery (csrc/griffinlim.hip): Speech2LinearSpec.recover (speechain/module/frontend/speech2linear.py:252-351).
  * The reference delegates the iteration to torchaudio.transforms.GriffinLim (:279-293; third party, absent); its published algorithm runs

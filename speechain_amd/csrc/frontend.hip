@@ -313,6 +313,76 @@ __global__ __launch_bounds__(256) void frontend_spec_finish_kernel(FrontendArgs 
   frontend_epilogue<32>(p, P, smem + p.off_O, b, t0, flen, tid, lane, wid);
 }
 
+// ---- the same in radix-4 form (n_fft a multiple of 4): a quarter of the product's flops ---------------------------------------------
+//   x[4 m + r] (r = 0..3) are four real sequences of Q = n_fft / 4 samples; with Y_r their Q-point DFTs,
+//     X[k] = sum_r e^{-2 pi i r k / n_fft} Y_r[k mod Q],       Y_r[Q - q] = conj(Y_r[q])  (real input: bins 0 .. Q / 2 suffice).
+//   frontend_frames4_kernel       frames4 (4 B T, Q): row 4 f + r = window[4 m + r] x sample(4 m + r) of frame f (the window can no
+//                                 longer be folded into the basis: the four sequences share it)
+//   sc_gemm (f32)                 spec4 (4 B T, 32 NTq) = frames4 x basis_Q (the unwindowed Q-point basis of sc_frontend_basis_init)
+//   frontend_spec_finish4_kernel  the twiddled sum over r, then power / magnitude into the image the shared epilogue reads
+// 4 x Q x (Q / 2 + 1) x 2 multiply-adds per frame instead of n_fft x (n_fft / 2 + 1) x 2: 0.59 instead of 2.16 MFLOP at n_fft = 1024.
+__global__ __launch_bounds__(256) void frontend_frames4_kernel(FrontendArgs p, const float* window, float* frames4) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const float* x = p.wave + (long long)b * p.wave_stride;
+  const long long wlen = p.wave_len[b];
+  const int len = (int)(wlen < p.T_w ? wlen : p.T_w);
+  const int limit = p.use_preemph ? len : p.T_w;
+  const float negc = p.use_preemph ? -p.preemph : 0.f;
+  const int Q = p.n_fft >> 2;
+  float* dst = frames4 + ((long long)b * p.T + t) * 4 * Q;
+  const int base = t * p.hop - p.pad;
+  for (int k = threadIdx.x; k < p.n_fft; k += 256) {
+    int n = base + k;
+    n = n < 0 ? -n : n;
+    n = n >= p.T_w ? 2 * (p.T_w - 1) - n : n;
+    const bool take = n < limit;
+    n = take ? n : 0;
+    const float c = x[n], q = x[n > 0 ? n - 1 : 0];
+    const float v = fmaf(negc, (p.use_preemph && take && n > 0) ? q : 0.f, take ? c : 0.f);
+    dst[(k & 3) * Q + (k >> 2)] = window[k] * v;
+  }
+}
+
+// twiddle (4, NB, 2) f64: cos, sin of 2 pi r k / n_fft.  The sum over r runs in double: a bin 100 dB below the frame's energy is the small
+// difference of four large terms, and float twiddles / float adds would put their own 6e-8 x |Y| on top of the transform's (measured on the
+// fixture's tone-plus-floor utterance: 7.8e-3 in log-mel with a float sum against the reference's own 6.3e-3).
+__global__ __launch_bounds__(256) void frontend_spec_finish4_kernel(FrontendArgs p, const float* spec4, const double* twiddle) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const long long wlen = p.wave_len[b];
+  long long flen_ll = floordiv_ll(wlen + 2LL * p.pad - p.n_fft, p.hop) + 1;
+  if (blockIdx.x == 0 && tid == 0) p.feat_len[b] = flen_ll;
+  const int flen = (int)(flen_ll < 0 ? 0 : (flen_ll > p.T ? p.T : flen_ll));
+  float* P = smem + p.off_P;
+  const int Q = p.n_fft >> 2;
+  const int NCq = ((Q / 2 + 1 + 15) / 16) * 32;  // columns of spec4: [16 cos | 16 sin] tiles of the Q-point transform's bins 0 .. Q / 2
+  for (int e = tid; e < 32 * p.NT * 16; e += 256) {
+    const int f = e / (p.NT * 16), k = e - f * (p.NT * 16);
+    float v = 0.f;
+    if (t0 + f < p.T && k < p.NB) {
+      const int q = k % Q;
+      const bool mirrored = q > Q / 2;
+      const int qq = mirrored ? Q - q : q;
+      const float* srow = spec4 + ((long long)b * p.T + t0 + f) * 4 * NCq + (qq >> 4) * 32 + (qq & 15);
+      double re = 0.0, im = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // (the basis columns hold cos and -sin: Re Y_r and Im Y_r; the mirrored bins are the conjugates)
+        const double yr = (double)srow[r * NCq], yi = mirrored ? -(double)srow[r * NCq + 16] : (double)srow[r * NCq + 16];
+        const double ct = twiddle[(r * p.NB + k) * 2], st = twiddle[(r * p.NB + k) * 2 + 1];
+        re += yr * ct + yi * st;  // (cos - i sin)(yr + i yi)
+        im += yi * ct - yr * st;
+      }
+      v = (float)(re * re + im * im);
+    }
+    P[f * p.PS + k] = p.mag_spec ? sqrtf(v) : v;
+  }
+  __syncthreads();
+  frontend_epilogue<32>(p, P, smem + p.off_O, b, t0, flen, tid, lane, wid);
+}
+
 // ---- n_fft = 400: Good-Thomas (prime-factor) two-stage DFT, 400 = 16 x 25 with gcd 1 -> no twiddle factors --------------
 //   input index  n = (25 n1 + 16 n2) mod 400,   output index  k = (225 k1 + 176 k2) mod 400   (CRT maps)
 //   stage 1: 25-point real-input DFTs along n2 for each n1 (k2 = 0..12 suffice: conjugate symmetry)
@@ -955,6 +1025,55 @@ SC_API int sc_frontend_frames(const float* wave, const long long* wave_len, int 
   a.n_fft = n_fft; a.krows = (n_fft + 1) & ~1; a.hop = hop; a.pad = pad; a.T = T;
   hipLaunchKernelGGL(frontend_frames_kernel, dim3(T, B), dim3(256), 0, stream, a, frames);
   SC_LAUNCH_CHECK("frontend_frames_kernel");
+  return SC_OK;
+}
+
+// frames4 (4 B T, n_fft / 4): row 4 f + r holds window[4 m + r] x sample(4 m + r) of frame f (radix-4 form of the wide transform; `window`
+// is the n_fft-long analysis window, zero-padded around win_length as torch.stft pads it).  n_fft a multiple of 4.
+SC_API int sc_frontend_frames4(const float* wave, const long long* wave_len, int B, int T_w, long long wave_stride, int use_preemph,
+                               float preemph, int n_fft, int hop, int center, int T, const float* window, float* frames4, hipStream_t stream) {
+  SC_CHECK_ARG(wave && wave_len && frames4 && window, "sc_frontend_frames4: null pointer");
+  SC_CHECK_ARG(B >= 1 && B <= 65535 && T_w >= 1 && n_fft >= 8 && n_fft % 4 == 0 && hop >= 1 && wave_stride >= T_w, "sc_frontend_frames4: bad sizes (n_fft a multiple of 4)");
+  const int pad = center ? n_fft / 2 : 0;
+  SC_CHECK_ARG((!center || pad < T_w) && T_w + 2 * pad >= n_fft && T == (T_w + 2 * pad - n_fft) / hop + 1, "sc_frontend_frames4: T=%d does not match the batch", T);
+  FrontendArgs a{};
+  a.wave = wave; a.wave_len = wave_len; a.wave_stride = wave_stride; a.T_w = T_w;
+  a.use_preemph = use_preemph; a.preemph = preemph;
+  a.n_fft = n_fft; a.krows = n_fft; a.hop = hop; a.pad = pad; a.T = T;
+  hipLaunchKernelGGL(frontend_frames4_kernel, dim3(T, B), dim3(256), 0, stream, a, window, frames4);
+  SC_LAUNCH_CHECK("frontend_frames4_kernel");
+  return SC_OK;
+}
+
+// spec4 (4 B T, 32 * sc_frontend_num_tiles(n_fft / 4)) f32 = frames4 x the unwindowed (n_fft / 4)-point basis -> the outputs of
+// sc_frontend_logmel_fwd; twiddle (4, n_fft / 2 + 1, 2) f64 = cos, sin of 2 pi r k / n_fft.  Other arguments as sc_frontend_spec_finish.
+SC_API int sc_frontend_spec_finish4(const float* spec4, const double* twiddle, const long long* wave_len, int B, int T_w, int n_fft, int hop,
+                                    int center, const float* melw, const int* band_lo, const int* band_hi, int n_mels, int mag_spec,
+                                    float clamp, int logging, float log_div, float* out_feat, float* out_energy, float* out_linear,
+                                    float lin_clamp, int lin_logging, float lin_log_div, long long* feat_len, int T, hipStream_t stream) {
+  SC_CHECK_ARG(spec4 && twiddle && wave_len && feat_len, "sc_frontend_spec_finish4: null pointer");
+  SC_CHECK_ARG(B >= 1 && B <= 65535 && T >= 1 && n_fft >= 8 && n_fft % 4 == 0 && hop >= 1, "sc_frontend_spec_finish4: bad sizes");
+  SC_CHECK_ARG(out_feat == nullptr || (melw && band_lo && band_hi && n_mels >= 1), "sc_frontend_spec_finish4: mel output needs melw/bands");
+  SC_CHECK_ARG(out_feat || out_linear || out_energy, "sc_frontend_spec_finish4: no output requested");
+  FrontendArgs a{};
+  a.wave_len = wave_len; a.T_w = T_w;
+  a.n_fft = n_fft; a.krows = n_fft; a.hop = hop; a.pad = center ? n_fft / 2 : 0; a.T = T;
+  a.NT = sc_frontend_num_tiles(n_fft); a.NB = n_fft / 2 + 1;
+  a.melw = melw; a.band_lo = band_lo; a.band_hi = band_hi; a.n_mels = out_feat ? n_mels : 0;
+  a.mag_spec = mag_spec; a.clamp = clamp; a.logging = logging; a.log_div = log_div;
+  a.log_scale = (float)(0.69314718055994530942 / (double)log_div);
+  a.out_feat = out_feat; a.out_energy = out_energy; a.out_linear = out_linear;
+  a.lin_clamp = lin_clamp; a.lin_logging = lin_logging; a.lin_log_div = lin_log_div;
+  a.feat_len = feat_len;
+  a.PS = a.NT * 16 + 1;
+  a.OS = (n_mels > 0 ? n_mels : 1) | 1;
+  a.off_P = 0;
+  a.off_O = (32 * a.PS + 3) & ~3;
+  const size_t smem = (size_t)(a.off_O + (out_feat ? 32 * a.OS : 0)) * sizeof(float);
+  SC_CHECK_ARG(smem <= 160 * 1024, "sc_frontend_spec_finish4: n_fft=%d needs %zu B of LDS (> 160 KiB)", n_fft, smem);
+  SC_HIP(hipFuncSetAttribute((const void*)frontend_spec_finish4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(frontend_spec_finish4_kernel, dim3(sc_cdiv(T, 32), B), dim3(256), smem, stream, a, spec4, twiddle);
+  SC_LAUNCH_CHECK("frontend_spec_finish4_kernel");
   return SC_OK;
 }
 

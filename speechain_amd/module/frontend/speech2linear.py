@@ -45,6 +45,25 @@ class StftPlan:
             self._basis[key] = basis
         return self._basis[key]
 
+    def radix4(self, device: torch.device):
+        """(window padded to n_fft as torch.stft pads it, unwindowed (n_fft / 4)-point basis, twiddles (4, n_fft / 2 + 1, 2)) for the radix-4
+        form of the wide transform (csrc/frontend.hip: sc_frontend_frames4 / sc_frontend_spec_finish4), built lazily per device."""
+        key = ("r4", device.type, device.index)
+        if key not in self._basis:
+            n, q = self.n_fft, self.n_fft // 4
+            win = getattr(torch, f"{self.window}_window")(self.win_length, dtype=torch.float32, device=device)
+            left = (n - self.win_length) // 2
+            wpad = torch.nn.functional.pad(win, (left, n - self.win_length - left)).contiguous()
+            ones = torch.ones(q, dtype=torch.float32, device=device)
+            bq = torch.empty(lib.value("sc_frontend_basis_floats", q), dtype=torch.float32, device=device)
+            lib.call("sc_frontend_basis_init", ptr(ones), q, q, self.hop, ptr(bq), stream())
+            r = torch.arange(4, dtype=torch.float64)[:, None]
+            k = torch.arange(n // 2 + 1, dtype=torch.float64)[None, :]
+            ang = 2.0 * math.pi * ((r * k) % n) / n
+            tw = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).to(device).contiguous()  # (float64: the finish kernel sums in double)
+            self._basis[key] = (wpad, bq, tw)
+        return self._basis[key]
+
     def synthesis(self, device: torch.device):
         """(window, inverse basis) for the overlap-add inverse transform (csrc/griffinlim.hip), built lazily per device."""
         key = ("inv", device.type, device.index)
@@ -95,6 +114,26 @@ def run_frontend(speech: torch.Tensor, speech_len: torch.Tensor, *, plan: StftPl
     feat_len = torch.empty(B, dtype=torch.int64, device=dev)
     log_div = 1.0 if log_base is None else math.log(log_base)
     lin_log_div = 1.0 if lin_log_base is None else math.log(lin_log_base)
+    if n_fft >= 512 and n_fft % 64 == 0 and os.environ.get("SC_FRONTEND_GEMM", "1") != "0" and os.environ.get("SC_FRONTEND_RADIX4", "0") == "1":
+        # OPT-IN (SC_FRONTEND_RADIX4=1): the wide transform in radix-4 form -- four (n_fft / 4)-point transforms per frame as ONE exact-f32 GEMM,
+        # twiddled sum (in double) in the finish kernel: a quarter of the flops of the direct product below, FastSpeech2 step 9.92 -> 9.67 ms.
+        # Not the default because it has an FFT's accuracy, not the direct product's: a bin 100 dB below the frame's energy becomes the small
+        # difference of four large float32 sub-transforms -- 8.1e-3 in log-mel on the fixture's tone-plus-floor utterance, where torch's own
+        # float32 FFT is 6.3e-3 from the exact value and the direct product 1e-4; the golden test holds the default path to 1e-3 + the
+        # reference's own deviation (tests/test_frontend_gpu.py).
+        q = n_fft // 4
+        ncq = 32 * lib.value("sc_frontend_num_tiles", q)
+        wpad, bq, tw = plan.radix4(dev)
+        frames4 = torch.empty(B * T * 4, q, dtype=torch.float32, device=dev)
+        lib.call("sc_frontend_frames4", ptr(wave), ptr(wave_len), B, T_w, wave.stride(0), 1 if preemphasis is not None else 0,
+                 float(preemphasis or 0.0), n_fft, hop, 1 if center else 0, T, ptr(wpad), ptr(frames4), stream())
+        spec4 = torch.empty(B * T * 4, ncq, dtype=torch.float32, device=dev)
+        lib.call("sc_gemm", 0, 0, 1, ptr(frames4), ptr(bq), ptr(spec4), B * T * 4, ncq, q, q, ncq, ncq, 1, 1, 0, 0, 0, 0, 0, 0, 1.0,
+                 None, 0, None, None, 0, 0, 0.0, None, 0, 0, 0, stream())
+        lib.call("sc_frontend_spec_finish4", ptr(spec4), ptr(tw), ptr(wave_len), B, T_w, n_fft, hop, 1 if center else 0, ptr(melw), ptr(lo), ptr(hi),
+                 n_mels, 1 if mag_spec else 0, float(clamp), 1 if logging else 0, log_div, ptr(mel), ptr(energy), ptr(lin), float(lin_clamp),
+                 1 if lin_logging else 0, lin_log_div, ptr(feat_len), T, stream())
+        return mel, lin, energy, feat_len
     if n_fft >= 512 and n_fft % 2 == 0 and os.environ.get("SC_FRONTEND_GEMM", "1") != "0":
         # wide transform: framing, the library's exact-f32 GEMM against the windowed-DFT basis, finish (csrc/frontend.hip)
         nc = 32 * lib.value("sc_frontend_num_tiles", n_fft)

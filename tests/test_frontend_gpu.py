@@ -48,6 +48,32 @@ def _err(a, b):
     return float((a.cpu() - b).abs().max())
 
 
+@pytest.mark.parametrize("tag,conf,n", [("tts", TTS, 3), ("odd", ODD, 2)])
+def test_radix4_transform_opt_in(golden, tag, conf, n, monkeypatch):
+    """SC_FRONTEND_RADIX4=1 (csrc/frontend.hip: four quarter-length transforms + twiddled sum, a quarter of the flops; off by default): the
+    same outputs as the default path to float32 accuracy on ordinary signals, and an FFT's accuracy -- within 1.5 x the reference's own
+    float32 deviation from the float64 evaluation, + 1e-3 -- on the tone-plus-floor utterance whose bins lie 100 dB below the frame energy."""
+    g = golden("g1_frontend")
+    m = _mod(conf, g[f"{tag}_melw"])
+    wave, wl = g["wave"][:n].cuda(), g["wave_len"][:n].cuda()
+    base = m(wave, wl)
+    monkeypatch.setenv("SC_FRONTEND_RADIX4", "1")
+    seen = []
+    from speechain_amd._lib import lib
+    orig = lib.call
+    monkeypatch.setattr(lib, "call", lambda name, *a: (seen.append(name), orig(name, *a))[1])
+    out = m(wave, wl)
+    assert "sc_frontend_spec_finish4" in seen and torch.equal(out[1], base[1])
+    kw = dict(conf)
+    kw.pop("return_energy", None)
+    truth, _ = R.speech2mel(g["wave"][:n].double().squeeze(-1), g["wave_len"][:n], explicit=True, mel_w=g[f"{tag}_melw"].double(), **kw)
+    for i in range(n):
+        ref_noise = float((g[f"{tag}_logmel"][i].double() - truth[i]).abs().max())
+        e64 = float((out[0][i].cpu().double() - truth[i]).abs().max())
+        print(f"  utt {i}: radix-4 |hip-f64| {e64:.2e}  |ref-f64| {ref_noise:.2e}  |radix4-default| {float((out[0][i] - base[0][i]).abs().max()):.2e}")
+        assert e64 < LOGMEL_TOL + 1.5 * ref_noise, (i, e64, ref_noise)
+
+
 @pytest.mark.parametrize("tag,conf,n", [("asr", ASR, 4), ("tts", TTS, 3), ("odd", ODD, 2)])
 def test_golden_logmel(golden, tag, conf, n):
     g = golden("g1_frontend")
