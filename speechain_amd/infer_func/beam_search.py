@@ -31,7 +31,9 @@ import torch
 from speechain_amd import functional as Fn
 from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
 
-_CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "1") == "1"  # (A/B knob)
+# (A/B knob.  Round 2: the CTC side of a position on a second stream, 88.0 -> 85.3 ms per batch.  Round 3: with the position's launches down from ~95
+#  to ~55 the fork and join of the branch inside the replayed graph (6-20 us each) cost more than the overlap gives: 59.2 -> 57.6 ms on ONE stream.)
+_CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "0") == "1"
 _FUSED_TAIL = os.environ.get("SC_DECODE_FUSED_TAIL", "1") == "1"  # (A/B knob: 0 = candidate matrix in HBM, separate top-k launches)
 _CTC_PSI_FAST = os.environ.get("SC_CTC_PSI_FAST", "1") == "1"  # (A/B knob: 0 = one v_exp per (row, token, frame))
 
@@ -135,9 +137,8 @@ class _Session:
         B, beam, V, w = self.B, self.beam, self.V, self.ctc_weight
         with torch.no_grad():
             # The CTC side of a step (forward variables of the rows chosen at the last step, then the prefix scores of all their extensions:
-            # 25 + 180 us, v_exp-bound) reads the tokens and its own state only -- it runs on a second stream next to the decoder's ~70
-            # launch-latency-sized kernels and joins in front of the candidate scores (88.0 -> 85.3 ms per batch; with the decoder's chain
-            # on a high-priority stream instead: 90-94 ms).  SC_DECODE_CTC_BRANCH=0: one stream.
+            # 25 + 100 us) reads the tokens and its own state only.  SC_DECODE_CTC_BRANCH=1 runs it on a second stream next to the decoder's
+            # launches and joins in front of the candidate scores (the default of round 2; see _CTC_BRANCH for why not any more).
             psi = None
             side = Fn._Side(self.x, tag="ctcdec") if (self.ctc and _CTC_BRANCH) else None
             if self.ctc:
