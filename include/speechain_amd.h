@@ -213,17 +213,17 @@ int sc_bn_act_bwd(int dtype, const void* z, const void* dy, long long M, int C, 
  * Replaces SpecAugment.forward after its random draws (speechain/module/augment/specaug.py:111-124 time warp,
  * :160-199 mask construction, :202-204 masked_fill).  in/out (B, T, F) f32.  warp_center < 0 disables the warp;
  * otherwise rows [0, warp_center) are resampled (bicubic, align_corners) onto [0, warp_pos) and rows
- * [warp_center, tmin) onto [warp_pos, tmin).  freq_/time_ len & pos are the (B, nf) / (B, nt) int64 tensors the
+ * [warp_center, tmin) onto [warp_pos, tmin); warp_mode 0 = bicubic (the default of the reference), 1 = bilinear (`time_warp_mode`, :23).  freq_/time_ len & pos are the (B, nf) / (B, nt) int64 tensors the
  * reference draws with torch.randint; a position is masked when pos <= x < pos + len for any of them.  Masked
  * elements get *fill (device scalar) or 0.0 when fill is null. */
-int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos, int warp_mode,
                    const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                    const long long* time_pos, int nt, const float* fill, hipStream_t stream);
 
 /* The same with the mean of the WARPED features as fill value (specaug.py:203, feat_norm off) in one call of two launches: the first warps
  * and leaves one sum per workgroup in `workspace` (sc_specaug_meanfill_workspace bytes), the second masks in place with their total / (B T F). */
 long long sc_specaug_meanfill_workspace(int B, int T);
-int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos, int warp_mode,
                             const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                             const long long* time_pos, int nt, void* workspace, long long ws_bytes, hipStream_t stream);
 

@@ -18,6 +18,7 @@ struct SpecAugArgs {
   int B, T, F;
   int tmin;
   int warp_center, warp_pos;  // warp_center < 0: no warp
+  int warp_mode;              // 0 bicubic (4 taps, A = -0.75), 1 bilinear (2 taps): F.interpolate's modes that take align_corners=True
   float scale_l, scale_r;
   const long long* freq_len;  // (B, nf) or null
   const long long* freq_pos;
@@ -100,10 +101,17 @@ __global__ __launch_bounds__(256) void specaug_kernel(SpecAugArgs p) {
         float lam = real - (float)i0;
         lam = fminf(fmaxf(lam, 0.f), 1.f);
         const float A = -0.75f;
-        w[0] = cubic_outer(lam + 1.f, A);
-        w[1] = cubic_inner(lam, A);
-        w[2] = cubic_inner(1.f - lam, A);
-        w[3] = cubic_outer(2.f - lam, A);
+        if (p.warp_mode == 1) {  // bilinear: (1 - lam) x[i0] + lam x[i0 + 1] (aten upsample_bilinear2d, the width axis is the identity here)
+          w[0] = 0.f;
+          w[1] = 1.f - lam;
+          w[2] = lam;
+          w[3] = 0.f;
+        } else {
+          w[0] = cubic_outer(lam + 1.f, A);
+          w[1] = cubic_inner(lam, A);
+          w[2] = cubic_inner(1.f - lam, A);
+          w[3] = cubic_outer(2.f - lam, A);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           int qi = i0 - 1 + j;
@@ -182,9 +190,10 @@ __global__ __launch_bounds__(256) void mel_log_kernel(const float* spec, long lo
 
 }  // namespace
 
-SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos, int warp_mode,
                           const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                           const long long* time_pos, int nt, const float* fill, hipStream_t stream) {
+  SC_CHECK_ARG(warp_mode == 0 || warp_mode == 1, "sc_specaug_fwd: warp_mode must be 0 (bicubic) or 1 (bilinear)");
   SC_CHECK_ARG(in && out, "sc_specaug_fwd: null pointer");
   SC_CHECK_ARG(B >= 1 && T >= 1 && F >= 1, "sc_specaug_fwd: bad shape (%d,%d,%d)", B, T, F);
   SC_CHECK_ARG(nf == 0 || (freq_len && freq_pos), "sc_specaug_fwd: nf=%d without index tensors", nf);
@@ -192,7 +201,7 @@ SC_API int sc_specaug_fwd(const float* in, float* out, int B, int T, int F, int 
   SC_CHECK_ARG(nf <= kMaxMasks * 64 && nt <= kMaxMasks * 64, "sc_specaug_fwd: too many masks");
   SpecAugArgs a{};
   a.in = in; a.out = out; a.B = B; a.T = T; a.F = F; a.tmin = tmin;
-  a.warp_center = warp_center; a.warp_pos = warp_pos;
+  a.warp_center = warp_center; a.warp_pos = warp_pos; a.warp_mode = warp_mode;
   if (warp_center >= 0) {
     SC_CHECK_ARG(in != out, "sc_specaug_fwd: the time warp cannot run in place");
     SC_CHECK_ARG(warp_pos >= 1 && warp_pos < tmin && warp_center >= 1 && warp_center < tmin && tmin <= T,
@@ -215,11 +224,12 @@ SC_API long long sc_specaug_meanfill_workspace(int B, int T) { return (long long
 
 // Warp, then mask with the mean of the warped features as fill value (specaug.py:111-124, :160-204 with feat_norm off) in one call: pass 1
 // warps in -> out and leaves one sum per workgroup, pass 2 masks out in place and every workgroup totals the sums for its fill value.
-SC_API int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos,
+SC_API int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, int F, int tmin, int warp_center, int warp_pos, int warp_mode,
                                    const long long* freq_len, const long long* freq_pos, int nf, const long long* time_len,
                                    const long long* time_pos, int nt, void* workspace, long long ws_bytes, hipStream_t stream) {
   SC_CHECK_ARG(in && out && workspace, "sc_specaug_fwd_meanfill: null pointer");
   SC_CHECK_ARG(in != out, "sc_specaug_fwd_meanfill: not in place");
+  SC_CHECK_ARG(warp_mode == 0 || warp_mode == 1, "sc_specaug_fwd_meanfill: warp_mode must be 0 (bicubic) or 1 (bilinear)");
   SC_CHECK_ARG(B >= 1 && T >= 1 && F >= 1 && F <= kMaxF, "sc_specaug_fwd_meanfill: bad shape (%d,%d,%d)", B, T, F);
   SC_CHECK_ARG(nf == 0 || (freq_len && freq_pos), "sc_specaug_fwd_meanfill: nf=%d without index tensors", nf);
   SC_CHECK_ARG(nt == 0 || (time_len && time_pos), "sc_specaug_fwd_meanfill: nt=%d without index tensors", nt);
@@ -227,7 +237,7 @@ SC_API int sc_specaug_fwd_meanfill(const float* in, float* out, int B, int T, in
   SC_CHECK_ARG(ws_bytes >= sc_specaug_meanfill_workspace(B, T), "sc_specaug_fwd_meanfill: workspace too small");
   SpecAugArgs a{};
   a.in = in; a.out = out; a.B = B; a.T = T; a.F = F; a.tmin = tmin;
-  a.warp_center = warp_center; a.warp_pos = warp_pos;
+  a.warp_center = warp_center; a.warp_pos = warp_pos; a.warp_mode = warp_mode;
   if (warp_center >= 0) {
     SC_CHECK_ARG(warp_pos >= 1 && warp_pos < tmin && warp_center >= 1 && warp_center < tmin && tmin <= T,
                  "sc_specaug_fwd_meanfill: bad warp (center=%d pos=%d tmin=%d T=%d)", warp_center, warp_pos, tmin, T);

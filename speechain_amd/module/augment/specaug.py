@@ -29,8 +29,9 @@ class SpecAugment(Module):
                     time_mask: bool = True, time_mask_width: Union[int, float, List] = 0.05, time_mask_num: int = 2,
                     time_mask_ratio: float = 1.0, feat_norm: bool = True):
         assert time_warp or freq_mask or time_mask, "You must specify at least one type of augmentation in SpecAugment!"
-        if time_warp and time_warp_mode != "bicubic":
-            raise NotImplementedError("speechain_amd SpecAugment implements the 'bicubic' time warp every recipe uses.")
+        if time_warp and time_warp_mode not in ("bicubic", "bilinear"):
+            # (the reference hands the mode to F.interpolate(..., align_corners=True) on a 4-D tensor, which accepts exactly these two)
+            raise ValueError(f"time_warp_mode must be 'bicubic' or 'bilinear' (F.interpolate with align_corners=True), got {time_warp_mode!r}")
         self.feat_dim = None
         if self.input_size is not None:
             self.feat_dim = self.input_size
@@ -129,6 +130,7 @@ class SpecAugment(Module):
         c = -1 if draws["warp_center"] is None else int(draws["warp_center"])
         p = -1 if draws["warp_pos"] is None else int(draws["warp_pos"])
         out = torch.empty_like(x)
+        wm = 1 if self.time_warp_mode == "bilinear" else 0
         tmin = int(draws["time_minlen"])
         masked = nf > 0 or nt > 0
         if masked and not self.feat_norm:
@@ -137,9 +139,9 @@ class SpecAugment(Module):
             if ws is None or ws[0] != (B, T, dev):
                 ws = ((B, T, dev), torch.empty(lib.value("sc_specaug_meanfill_workspace", B, T), dtype=torch.uint8, device=dev))
                 self.__dict__["_meanfill_ws"] = ws  # (reused: the calls of one module are ordered on its stream)
-            lib.call("sc_specaug_fwd_meanfill", ptr(x), ptr(out), B, T, Fd, tmin, c, p, fl, fp, nf, tl, tp, nt, ptr(ws[1]), ws[1].numel(), stream())
+            lib.call("sc_specaug_fwd_meanfill", ptr(x), ptr(out), B, T, Fd, tmin, c, p, wm, fl, fp, nf, tl, tp, nt, ptr(ws[1]), ws[1].numel(), stream())
         else:
-            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, fl, fp, nf, tl, tp, nt, None, stream())
+            lib.call("sc_specaug_fwd", ptr(x), ptr(out), B, T, Fd, tmin, c, p, wm, fl, fp, nf, tl, tp, nt, None, stream())
         if done is not None:
             done.record()  # (the staging buffer is free once these kernels have run)
         return out

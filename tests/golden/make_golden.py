@@ -167,6 +167,7 @@ def g2_specaug():
         default=dict(),
         nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
         warponly=dict(freq_mask=False, time_mask=False),
+        bilinear=dict(time_warp_mode="bilinear", freq_mask_width=15, freq_mask_num=2, time_mask_width=0.05, time_mask_num=2),
     )
     for ci, (name, conf) in enumerate(cases.items()):
         mod = SpecAugment(input_size=80, **conf)

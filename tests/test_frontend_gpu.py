@@ -229,6 +229,7 @@ SPECAUG_CASES = dict(
     default=dict(),
     nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
     warponly=dict(freq_mask=False, time_mask=False),
+    bilinear=dict(time_warp_mode="bilinear", freq_mask_width=15, freq_mask_num=2, time_mask_width=0.05, time_mask_num=2),
 )
 
 

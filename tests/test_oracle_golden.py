@@ -56,6 +56,7 @@ SPECAUG_CASES = dict(
     default=dict(),
     nowarp_mean=dict(time_warp=False, feat_norm=False, freq_mask_width=[2, 9], time_mask_width=[3, 12]),
     warponly=dict(freq_mask=False, time_mask=False),
+    bilinear=dict(time_warp_mode="bilinear", freq_mask_width=15, freq_mask_num=2, time_mask_width=0.05, time_mask_num=2),
 )
 
 
@@ -64,6 +65,7 @@ def test_specaug_draws_bit_exact_and_output(golden, name):
     g = golden("g2_specaug")
     conf = dict(SPECAUG_CASES[name])
     feat_norm = conf.pop("feat_norm", True)
+    mode = conf.pop("time_warp_mode", "bicubic")
     torch.manual_seed(int(g[f"{name}_seed"]))
     d = R.specaug_draw(g["feat_len"], 3, 80, **conf)
     drawn = [x for x in (d["warp_center"], d["warp_pos"], d["freq_len"], d["freq_pos"], d["time_len"], d["time_pos"])
@@ -72,8 +74,8 @@ def test_specaug_draws_bit_exact_and_output(golden, name):
     for j, x in enumerate(drawn):
         ref = g[f"{name}_draw{j}"]
         assert torch.equal(torch.as_tensor(x).reshape(ref.shape), ref), (name, j)
-    for explicit in (False, True):
-        out = R.specaug_apply(g["feat"], g["feat_len"], d, feat_norm=feat_norm, explicit_warp=explicit)
+    for explicit in ((False, True) if mode == "bicubic" else (False,)):  # (the explicit resampler restates the cubic kernel only)
+        out = R.specaug_apply(g["feat"], g["feat_len"], d, time_warp_mode=mode, feat_norm=feat_norm, explicit_warp=explicit)
         close(out, g[f"{name}_out"], atol=1e-4 if explicit else 1e-6)
 
 
