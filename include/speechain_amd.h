@@ -479,6 +479,12 @@ int sc_ce_fwd(int dtype, const void* logits, const long long* target, long long 
 int sc_ce_bwd(int dtype, const void* logits, const long long* target, const float* lse, const float* grow, long long R, int V,
               long long ld, float temperature, float smoothing, void* dlogits, hipStream_t stream);
 
+/* The reduction of the per-token losses to the criterion's scalar (cross_entropy.py:201-212, no token weights, no confidence filter) in one
+ * launch: loss = mean_b( sum_{l < len[b]} rows[b][l] / (len[b] + 1e-10) ) (length_normalized = 0: without the division); and
+ * grow[b][l] = g / (B (len[b] + 1e-10)) for l < len[b], else 0, for an upstream scalar g on the device. */
+int sc_seq_loss_fwd(const float* rows, const long long* len, int B, int L, int length_normalized, float* loss, hipStream_t stream);
+int sc_seq_loss_bwd(const float* g, const long long* len, int B, int L, int length_normalized, float* grow, hipStream_t stream);
+
 /* lse[r] = logsumexp_v logits[r][v] */
 int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream);
 

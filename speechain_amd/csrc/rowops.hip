@@ -760,6 +760,40 @@ __global__ __launch_bounds__(256) void row_lse_vec_kernel(const unsigned short* 
   }
 }
 
+// loss = mean_b( sum_{l < len[b]} rows[b][l] / (len[b] + 1e-10) )   (length_normalized; else without the division): the reduction of the
+// per-token losses of speechain/criterion/cross_entropy.py:201-212 in ONE launch (one workgroup; (B, L) is a few thousand floats) instead of
+// mask construction, masked_fill, sum, divide and mean -- eight small launches on the path between the forward and the backward pass, and
+// eight more coming back.
+__global__ __launch_bounds__(256) void seq_loss_fwd_kernel(const float* rows, const long long* len, int B, int L, int length_normalized, float* loss) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int b = threadIdx.x >> 6; b < B; b += 4) {  // one wave per sentence
+    const int n = (int)min((long long)L, max(0LL, len[b]));
+    float s = 0.f;
+    for (int l = threadIdx.x & 63; l < n; l += 64) s += rows[(long long)b * L + l];
+    s = sc_wave_sum(s);
+    if (length_normalized) s = s / ((float)len[b] + 1e-10f);
+    if ((threadIdx.x & 63) == 0) acc += (double)s;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; i += 64) t += red[i];
+    loss[0] = (float)(t / (double)B);
+  }
+}
+
+// grow[b][l] = g / (B (len[b] + 1e-10)) for l < len[b], else 0
+__global__ __launch_bounds__(256) void seq_loss_bwd_kernel(const float* g, const long long* len, int B, int L, int length_normalized, float* grow) {
+  const float gv = g[0] / (float)B;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < (long long)B * L; i += 256LL * gridDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (long long)b * L);
+    const float d = length_normalized ? (float)len[b] + 1e-10f : 1.f;
+    grow[i] = l < len[b] ? gv / d : 0.f;
+  }
+}
+
 }  // namespace
 
 #define SC_DISPATCH_TN(dtype, n, KERNEL, N0, N1, N2, ...)                                                  \
@@ -990,5 +1024,20 @@ SC_API int sc_row_lse(int dtype, const void* logits, long long R, int V, long lo
   else
     SC_DISPATCH_T(dtype, row_lse_kernel, dim3((unsigned)R), dim3(256), 0, stream, logits, R, V, ld, lse);
   SC_LAUNCH_CHECK("row_lse_kernel");
+  return SC_OK;
+}
+
+// Masked, length-normalised mean of per-token losses (speechain/criterion/cross_entropy.py:201-212 without token weights / confidence
+// filtering): rows (B, L) f32, len (B) int64 -> loss (1) f32; and its gradient with respect to rows for an upstream scalar g (device).
+SC_API int sc_seq_loss_fwd(const float* rows, const long long* len, int B, int L, int length_normalized, float* loss, hipStream_t stream) {
+  SC_CHECK_ARG(rows && len && loss && B >= 1 && L >= 1, "sc_seq_loss_fwd: bad arguments");
+  hipLaunchKernelGGL(seq_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, rows, len, B, L, length_normalized, loss);
+  SC_LAUNCH_CHECK("seq_loss_fwd_kernel");
+  return SC_OK;
+}
+SC_API int sc_seq_loss_bwd(const float* g, const long long* len, int B, int L, int length_normalized, float* grow, hipStream_t stream) {
+  SC_CHECK_ARG(g && len && grow && B >= 1 && L >= 1, "sc_seq_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(seq_loss_bwd_kernel, dim3((unsigned)sc_cdiv(B * L, 256)), dim3(256), 0, stream, g, len, B, L, length_normalized, grow);
+  SC_LAUNCH_CHECK("seq_loss_bwd_kernel");
   return SC_OK;
 }

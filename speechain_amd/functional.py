@@ -1537,6 +1537,36 @@ def cross_entropy_rows(logits2, target, smoothing: float, temperature: float = 1
     return _CrossEntropyRows.apply(logits2, target, float(smoothing), float(temperature))
 
 
+class _SeqLoss(torch.autograd.Function):
+    """mean over the sentences of the (length-normalised) sum of their valid per-token losses, one launch each way (sc_seq_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, rows, text_len, length_normalized):
+        require_gpu(rows, "sequence loss")
+        rows = rows.float().contiguous()
+        B, L = rows.shape
+        tl = text_len.to(device=rows.device, dtype=torch.int64).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=rows.device)
+        lib.call("sc_seq_loss_fwd", _p(rows), _p(tl), B, L, 1 if length_normalized else 0, _p(loss), stream())
+        ctx.save_for_backward(tl)
+        ctx.meta = (B, L, length_normalized)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (tl,) = ctx.saved_tensors
+        B, L, ln = ctx.meta
+        g1 = g.float().reshape(1).contiguous()
+        grow = torch.empty(B, L, dtype=torch.float32, device=g.device)
+        lib.call("sc_seq_loss_bwd", _p(g1), _p(tl), B, L, 1 if ln else 0, _p(grow), stream())
+        return grow, None, None
+
+
+def seq_loss(rows: torch.Tensor, text_len: torch.Tensor, length_normalized: bool) -> torch.Tensor:
+    """Scalar criterion value from (B, L) per-token losses and the sentence lengths (cross_entropy.py:201-212 without its options)."""
+    return _SeqLoss.apply(rows, text_len, bool(length_normalized))
+
+
 class _CTC(torch.autograd.Function):
     """Per-utterance CTC negative log-likelihood (B,) float32 with zero_infinity handling."""
 
