@@ -244,7 +244,11 @@ __device__ long long sc_attn_probe[8 * 8 * 8];
 typedef __attribute__((address_space(1))) const void* at_gptr_t;
 typedef __attribute__((address_space(3))) void* at_lptr_t;
 
-template <bool DROP>
+// SPLIT (at most 32 queries per (batch, head): the encoder-decoder attention of a decoding position, beams as queries): all four waves
+// hold the SAME 32 queries and take every fourth key tile each -- wave w stages tiles w, w + 4, ... into a region of its own (no barrier in
+// the sweep) -- and wave 0 merges the four partial (maximum, sum, O) triples at the end.  The unsplit form gives such a launch to one wave:
+// four dependent key tiles, ~12 us for 0.26 GFLOP.  No causal mask, no dropout in this form (checked on the host).
+template <bool DROP, bool SPLIT = false>
 __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   constexpr int KT = 64, STAGES = 3, TILE = KT * DH, STAGE_ELEMS = 2 * TILE;  // K tile + V tile per stage (16 KB)
   extern __shared__ __attribute__((aligned(1024))) unsigned short dsm[];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
     }
   }
   const int b = z / p.H, hd = z - b * p.H;
-  const int qg = qt * 128 + wid * 32 + li;  // this lane's query
+  const int qg = SPLIT ? qt * 32 + li : qt * 128 + wid * 32 + li;  // this lane's query
   const int qc = min(qg, p.Tq - 1);
   const unsigned short* Kg = p.K + b * p.kv_b + hd * DH;
   const unsigned short* Vg = p.V + b * p.kv_b + hd * DH;
@@ -275,9 +279,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   const int grow = lane >> 3, gch = (lane & 7) ^ (grow & 7);
 #define AT_ISSUE(T)                                                                                                      \
   do {                                                                                                                   \
-    unsigned short* st_ = dsm + ((T) % STAGES) * STAGE_ELEMS;                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                   \
-      const int g_ = 2 * wid + i_;                                                                                       \
+    unsigned short* st_ = dsm + (SPLIT ? wid : (T) % STAGES) * STAGE_ELEMS; /* (SPLIT: the wave's own region, all 8 granules) */ \
+    _Pragma("unroll") for (int i_ = 0; i_ < (SPLIT ? 8 : 2); ++i_) {                                                     \
+      const int g_ = SPLIT ? i_ : 2 * wid + i_;                                                                          \
       const long long src_ = (long long)min((T) * KT + g_ * 8 + grow, p.Tk - 1) * p.ldk + gch * 8;                       \
       __builtin_amdgcn_global_load_lds((at_gptr_t)(Kg + src_), (at_lptr_t)(st_ + g_ * 512), 16, 0, 0);                   \
       __builtin_amdgcn_global_load_lds((at_gptr_t)(Vg + src_), (at_lptr_t)(st_ + TILE + g_ * 512), 16, 0, 0);            \
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   const unsigned thr = sc_drop_threshold(p.drop_p);
   // pair index of this lane's (query, key 64 t + kb + 4 h), kb even: pairq + 32 t + kb / 2
   const unsigned long long pairq = ((p.offset + ((unsigned long long)z * p.Tq + qc) * p.ldp) >> 1) + (unsigned)(2 * h);
-  const int qwave0 = qt * 128 + wid * 32;  // first query of the wave
+  const int qwave0 = SPLIT ? qt * 32 : qt * 128 + wid * 32;  // first query of the wave
 
   f32x16 o[2];
 #pragma unroll
@@ -311,18 +315,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
     for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;  // l_run: this lane half's share of the row sum
 
-  bool kok = key_ok(0);
-  if (nt > 0) AT_ISSUE(0);
-  if (nt > 1) AT_ISSUE(1);
-  for (int t = 0; t < nt; ++t) {
+  bool kok = key_ok(SPLIT ? wid : 0);
+  if (!SPLIT) {
+    if (nt > 0) AT_ISSUE(0);
+    if (nt > 1) AT_ISSUE(1);
+  }
+  for (int t = SPLIT ? wid : 0; t < nt; t += SPLIT ? 4 : 1) {
     AT_PROBE(t, 0);
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    AT_PROBE(t, 1);
-    const bool kok_next = (t + 1 < nt) ? key_ok(t + 1) : false;
-    if (t + 2 < nt) AT_ISSUE(t + 2);
-    const unsigned short* ks_ = dsm + (t % STAGES) * STAGE_ELEMS;
+    bool kok_next;
+    if (SPLIT) {  // this wave's own tile: request, wait, no barrier (nobody else touches the region)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads of the wave's previous tile are done)
+      AT_ISSUE(t);
+      kok_next = (t + 4 < nt) ? key_ok(t + 4) : false;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      AT_PROBE(t, 1);
+      kok_next = (t + 1 < nt) ? key_ok(t + 1) : false;
+      if (t + 2 < nt) AT_ISSUE(t + 2);
+    }
+    const unsigned short* ks_ = dsm + (SPLIT ? wid : t % STAGES) * STAGE_ELEMS;
     const unsigned short* vs_ = ks_ + TILE;
     // key validity of the tile as a 64-bit lane mask
     const unsigned long long bits = __ballot(kok);
@@ -422,6 +436,47 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(AttnArgs p) {
   }
 #undef AT_ISSUE
   AT_PROBE(7, 1);
+
+  if (SPLIT) {
+    // ---- merge: every wave leaves (m, l, O) of its key tiles in its own region, lane by lane (the four waves hold the same queries in the
+    //      same registers); wave 0 rescales them to the common maximum and sums ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* part = (float*)(dsm + wid * STAGE_ELEMS);  // [34][64]: m, l, o[0][0..15], o[1][0..15], lane-contiguous (conflict-free)
+    part[0 * 64 + lane] = m_run;
+    part[1 * 64 + lane] = l_run;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(2 + 16 * j + r) * 64 + lane] = o[j][r];
+    __syncthreads();
+    if (wid != 0) return;
+    float mw[4], lw[4];
+    float mstar = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* pw = (const float*)(dsm + w * STAGE_ELEMS);
+      mw[w] = pw[0 * 64 + lane];
+      lw[w] = pw[1 * 64 + lane];
+      mstar = fmaxf(mstar, mw[w]);
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - mstar);
+      const float* pw = (const float*)(dsm + w * STAGE_ELEMS);
+      lsum += lw[w] * f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = fmaf(pw[(2 + 16 * j + r) * 64 + lane], f, o[j][r]);
+    }
+    m_run = mstar;
+    l_run = lsum;
+  }
 
   // ---- normalise and store: lane (query, half h) holds head dims 32 j + 8 (r >> 2) + 4 h + (r & 3) ----
   {
@@ -1013,6 +1068,14 @@ SC_API int sc_attention_fwd(const void* Q, const void* K, const void* V, void* O
   a.mask = mask; a.mask_b = mask_b; a.mask_q = mask_q; a.causal = causal;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.ldp = (Tk + 7) / 8 * 8; a.scale = scale; a.drop_p = drop_p; a.drop_keep = 1.f / (1.f - drop_p);
   a.seed = seed; a.offset = offset;
+  static const bool split_ok = getenv("SC_ATTN_NO_SPLIT") == nullptr;  // (A/B knob)
+  if (stream_ok && split_ok && Tq <= 32 && Tk > 64 && !causal && drop_p == 0.f) {
+    // few queries against many keys (a decoding position's encoder-decoder attention): the four waves split the key tiles
+    const size_t smem4 = (size_t)4 * 2 * 64 * DH * sizeof(unsigned short);  // one 16 KB region per wave
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<false, true>), dim3(1, B * H), dim3(256), smem4, stream, a);
+    SC_LAUNCH_CHECK("attn_fwd_stream_kernel<split>");
+    return SC_OK;
+  }
   if (stream_ok) {
     const size_t smem_s = (size_t)3 * 2 * 64 * DH * sizeof(unsigned short);  // three 16 KB stages
     if (drop_p > 0.f) hipLaunchKernelGGL(attn_fwd_stream_kernel<true>, dim3(sc_cdiv(Tq, 128), B * H), dim3(256), smem_s, stream, a);

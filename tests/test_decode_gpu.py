@@ -321,6 +321,39 @@ def test_fused_step_tail_equals_the_separate_launches(dtype, ctc, eos_stats):
     assert int((tok_b == eos).sum()) == 0  # no row continues with <sos/eos>
 
 
+@pytest.mark.parametrize("B,Tq,H,Tk", [(32, 16, 8, 256), (3, 4, 2, 77), (2, 32, 8, 1030), (5, 1, 4, 65), (2, 16, 2, 700)])
+def test_few_queries_against_many_keys_split_over_the_waves(B, Tq, H, Tk):
+    """The encoder-decoder attention of a decoding position (<= 32 queries per sentence and head, beams as queries): the four waves of
+    `attn_fwd_stream_kernel<false, true>` take every fourth key tile each and merge their partial softmaxes.  Against fp32 softmax attention
+    on the same bf16 operands, ragged encoder lengths (tiles without a live key included), and against the unsplit kernel (SC_ATTN_NO_SPLIT
+    is read once per process, so the comparison is with fp32 only here)."""
+    from speechain_amd import functional as Fn
+
+    g = torch.Generator().manual_seed(B * 100 + Tk)
+    d = H * 64
+    q = torch.randn(B, Tq, d, generator=g).bfloat16().cuda()
+    kv = torch.randn(B, Tk, 2 * d, generator=g).bfloat16().cuda()
+    lens = torch.randint(max(1, Tk // 5), Tk + 1, (B,), generator=g)
+    lens[0] = Tk
+    mask = (torch.arange(Tk)[None, :] < lens[:, None])[:, None, :].cuda()
+    scale = 0.125
+    Fn.set_compute_dtype(torch.bfloat16)
+    Fn.set_attention_probs(False)
+    try:
+        with torch.no_grad():
+            out, _ = Fn.attention_core(q, kv, 0, 0, 1, H, d, mask, False, scale, 0.0)
+        qf = q.float().view(B, Tq, H, 64).permute(0, 2, 1, 3)
+        kf = kv.float()[..., :d].view(B, Tk, H, 64).permute(0, 2, 1, 3)
+        vf = kv.float()[..., d:].view(B, Tk, H, 64).permute(0, 2, 1, 3)
+        sc = ((qf @ kf.transpose(-1, -2)) * scale).masked_fill(~mask[:, :, None, :], float("-inf"))
+        ref = (torch.softmax(sc, dim=-1) @ vf).permute(0, 2, 1, 3).reshape(B, Tq, d)
+        e = float((out.float() - ref).norm() / ref.norm())
+        assert e < 8e-3, e  # (bf16 probabilities and output, as the training kernel: 4e-3 measured)
+    finally:
+        Fn.set_compute_dtype(None)
+        Fn.set_attention_probs(True)
+
+
 def test_replayed_decoding_follows_parameter_updates():
     """The per-position hipGraphs of a decoding session read the cached bf16 weight copies by address and never run the layers' host-side
     lookups again: after an in-place parameter update (a training step between two validation decodes) the replayed search must use the new
