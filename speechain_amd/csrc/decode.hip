@@ -116,6 +116,16 @@ template <> struct Chunk<unsigned short> {
   }
 };
 
+// Sum over aligned groups of G lanes (8 or 16), DPP only; the group's last lane holds the total (every lane of a group of 8 does).
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  v += sc_dpp<0xB1, 0xF>(0.f, v);   // quad_perm [1,0,3,2]
+  v += sc_dpp<0x4E, 0xF>(0.f, v);   // quad_perm [2,3,0,1]
+  v += sc_dpp<0x141, 0xF>(0.f, v);  // row_half_mirror
+  if (G == 16) v += sc_dpp<0x140, 0xF>(0.f, v);  // row_mirror
+  return v;
+}
+
 // qkv: (N, 3 d) this step's projections [q | k | v]; cache: (N, Tmax, 2 d) [k | v]; table: (N, Tmax); out: (N, d).
 // grid (ceil(N H / 4)); one wave per (row, head).  A key's 64 head dimensions are spread over LPK lanes of 16 bytes each, so that every
 // load instruction reads KPI = 64 / LPK whole rows (8 for bf16, 4 for f32); scores and probabilities pass through a per-wave LDS row.
@@ -148,23 +158,44 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long lon
   float qc[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) qc[e] = qs[sub * EPL + e];
-  // ---- scores of the history ----
-  for (int k0 = 0; k0 < pos; k0 += KPI) {
-    const int key = k0 + grp;
-    float part = 0.f;
-    int r = 0;
-    if (key < pos) {
-      r = trow[key];
-      float kv[EPL];
-      Chunk<T>::ld(cache + ((long long)r * Tmax + key) * (2 * d) + h * DH + sub * EPL, kv);
+  // ---- the ancestry row into LDS: one round trip for all keys; every cache address below comes from it ----
+  for (int t = lane; t < pos; t += 64) rs[t] = trow[t];
+  asm volatile("" ::: "memory");
+  // Keys and values are fetched in batches of U load instructions (U KPI keys), one batch ahead of the arithmetic; lanes past the history
+  // re-read key pos - 1 and drop the result, which keeps the loads free of branches.
+  constexpr int U = 4, KPB = KPI * U;
+  const T* kbase = cache + h * DH + sub * EPL;
+  auto fetch = [&](int k0, long long off, float (&dst)[U][EPL]) {
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) part = fmaf(kv[e], qc[e], part);
+    for (int u = 0; u < U; ++u) {
+      const int kc = min(k0 + u * KPI + grp, pos - 1);
+      Chunk<T>::ld(kbase + ((long long)rs[kc] * Tmax + kc) * (2 * d) + off, dst[u]);
     }
+  };
+  float kb[U][EPL], vb[U][EPL];
+  if (pos > 0) {
+    fetch(0, 0, kb);
+    fetch(0, d, vb);  // the first batch of values travels during the scores and the softmax
+  }
+  // ---- scores of the history ----
+  for (int k0 = 0; k0 < pos; k0 += KPB) {
+    float nx[U][EPL];
+    const bool more = k0 + KPB < pos;
+    if (more) fetch(k0 + KPB, 0, nx);
 #pragma unroll
-    for (int o = 1; o < LPK; o <<= 1) part += __shfl_xor(part, o, 64);
-    if (sub == 0 && key < pos) {
-      ss[key] = part * scale;
-      rs[key] = r;
+    for (int u = 0; u < U; ++u) {
+      const int key = k0 + u * KPI + grp;
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) part = fmaf(kb[u][e], qc[e], part);
+      part = group_sum<LPK>(part);
+      if (sub == LPK - 1 && key < pos) ss[key] = part * scale;
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) kb[u][e] = nx[u][e];
     }
   }
   if (lane == 0) ss[pos] = s_new;
@@ -185,14 +216,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long lon
   float acc[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-  for (int k0 = 0; k0 < pos; k0 += KPI) {
-    const int key = k0 + grp;
-    if (key < pos) {
-      const float pk = ss[key];
-      float vv[EPL];
-      Chunk<T>::ld(cache + ((long long)rs[key] * Tmax + key) * (2 * d) + d + h * DH + sub * EPL, vv);
+  for (int k0 = 0; k0 < pos; k0 += KPB) {
+    float nx[U][EPL];
+    const bool more = k0 + KPB < pos;
+    if (more) fetch(k0 + KPB, d, nx);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
+    for (int u = 0; u < U; ++u) {
+      const int key = k0 + u * KPI + grp;
+      const float pk = key < pos ? ss[key] : 0.f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, vb[u][e], acc[e]);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) vb[u][e] = nx[u][e];
     }
   }
 #pragma unroll
