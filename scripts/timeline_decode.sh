@@ -14,7 +14,7 @@ f = sorted(glob.glob('gpurun_out/timeline/decode/*/*kernel_trace.csv'))[-1]
 rd = list(csv.DictReader(open(f)))
 qk = 'Stream_Id' if 'Stream_Id' in rd[0] else 'Queue_Id'
 rows = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', ''), r[qk]) for r in rd)
-adv = [i for i, r in enumerate(rows) if 'beam_advance_kernel' in r[2]]
+adv = [i for i, r in enumerate(rows) if 'advance_kernel' in r[2]]
 print(len(adv), "positions in the trace")
 # positions 40..60 of the last replayed batch but one (the very last batch is the instrumented eager one)
 per = 82

@@ -94,11 +94,15 @@ template <> struct Chunk<float> {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
   }
   static __device__ __forceinline__ void st(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+  static __device__ __forceinline__ uint4 raw(const float* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ void unpack(const uint4& a, float* v) {
+    v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+  }
 };
 template <> struct Chunk<unsigned short> {
   static constexpr int EPL = 8;
-  static __device__ __forceinline__ void ld(const unsigned short* p, float* v) {
-    const uint4 a = *(const uint4*)p;
+  static __device__ __forceinline__ uint4 raw(const unsigned short* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ void unpack(const uint4& a, float* v) {
     const unsigned w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -106,6 +110,7 @@ template <> struct Chunk<unsigned short> {
       v[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
     }
   }
+  static __device__ __forceinline__ void ld(const unsigned short* p, float* v) { unpack(raw(p), v); }
   static __device__ __forceinline__ void st(unsigned short* p, const float* v) {
     uint4 a;
     a.x = sc_f32_to_bf16(v[0]) | ((unsigned)sc_f32_to_bf16(v[1]) << 16);
@@ -127,122 +132,113 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // qkv: (N, 3 d) this step's projections [q | k | v]; cache: (N, Tmax, 2 d) [k | v]; table: (N, Tmax); out: (N, d).
-// grid (ceil(N H / 4)); one wave per (row, head).  A key's 64 head dimensions are spread over LPK lanes of 16 bytes each, so that every
-// load instruction reads KPI = 64 / LPK whole rows (8 for bf16, 4 for f32); scores and probabilities pass through a per-wave LDS row.
+// One wave per (row, head), 4 per workgroup (see the XCD placement below).  A key's 64 head dimensions are spread over LPK lanes of 16 bytes each, so that every
+// load instruction reads KPI = 64 / LPK whole rows (8 for bf16, 4 for f32); the probabilities never leave the lanes that multiply the values.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const T* qkv, long long ldqkv, T* cache, const int* table, T* out, long long ldo,
                                                           int N, int H, int Tmax, int pos, float scale) {
   constexpr int EPL = Chunk<T>::EPL, LPK = DH / EPL, KPI = 64 / LPK;
-  extern __shared__ __attribute__((aligned(16))) float dsm_dec[];  // per wave: q[64], v_new[64], s[Tmax], rows[Tmax]
+  extern __shared__ __attribute__((aligned(16))) float dsm_dec[];  // per wave: q[64], v_new[64], rows[Tmax]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int gw = blockIdx.x * 4 + w;
-  if (gw >= N * H) return;
-  float* qs = dsm_dec + (size_t)w * (2 * DH + 2 * Tmax);
+  // Workgroups go to the 8 XCDs round-robin.  The rows of one sentence's beam are neighbours and share most of their ancestry, so the 16 rows
+  // n0 .. n0 + 15 of one head (4 workgroups) are placed on one XCD back to back: the shared cache rows then come out of that XCD's L2.
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int g = (seq >> 2) * 8 + xcd;  // (chunk of 16 rows, head)
+  const int n = (g / H) * 16 + (seq & 3) * 4 + w, h = g % H;
+  if (n >= N) return;
+  float* qs = dsm_dec + (size_t)w * (2 * DH + Tmax);
   float* vs = qs + DH;
-  float* ss = vs + DH;
-  int* rs = (int*)(ss + Tmax);
-  const int n = gw / H, h = gw - n * H;
+  int* rs = (int*)(vs + DH);
   const int d = H * DH;
+  // The kernel is a chain of memory round trips, so there are as few as the data flow allows: [this step's q, k, v and the ancestry row],
+  // then [keys and values of the first two batches], then one batch ahead of the arithmetic.
+  const int* trow = table + (long long)n * Tmax;
+  const int t0 = lane < pos ? trow[lane] : 0;
   const T* row = qkv + (long long)n * ldqkv + h * DH;
   const float q = Elem<T>::ld(row + lane), kn = Elem<T>::ld(row + d + lane), vn = Elem<T>::ld(row + 2 * d + lane);
+  if (lane < pos) rs[lane] = t0;
+  for (int t = lane + 64; t < pos; t += 64) rs[t] = trow[t];
   // append this position: slot (n, pos)
   T* slot = cache + ((long long)n * Tmax + pos) * (2 * d) + h * DH;
   Elem<T>::st(slot + lane, kn);
   Elem<T>::st(slot + d + lane, vn);
   qs[lane] = q;
   vs[lane] = vn;
-  const float s_new = sc_wave_sum(q * kn) * scale;  // the new position's own score (its key is still in registers)
   asm volatile("" ::: "memory");  // (the wave reads its own LDS rows below; LDS operations of one wave complete in order)
-  const int* trow = table + (long long)n * Tmax;
   const int sub = lane % LPK, grp = lane / LPK;
-  float qc[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) qc[e] = qs[sub * EPL + e];
-  // ---- the ancestry row into LDS: one round trip for all keys; every cache address below comes from it ----
-  for (int t = lane; t < pos; t += 64) rs[t] = trow[t];
-  asm volatile("" ::: "memory");
-  // Keys and values are fetched in batches of U load instructions (U KPI keys), one batch ahead of the arithmetic; lanes past the history
-  // re-read key pos - 1 and drop the result, which keeps the loads free of branches.
+  // A key's 64 head dimensions are spread over LPK lanes of 16 bytes each: one load instruction reads KPI whole rows (8 for bf16, 4 for
+  // f32), a batch is U instructions for the keys and U for the values.  Lanes past the history re-read key pos - 1 and give it the score
+  // -inf, which keeps the loads free of branches.
   constexpr int U = 4, KPB = KPI * U;
   const T* kbase = cache + h * DH + sub * EPL;
-  auto fetch = [&](int k0, long long off, float (&dst)[U][EPL]) {
+  auto fetch = [&](int k0, uint4 (&kd)[U], uint4 (&vd)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kc = min(k0 + u * KPI + grp, pos - 1);
-      Chunk<T>::ld(kbase + ((long long)rs[kc] * Tmax + kc) * (2 * d) + off, dst[u]);
+      const T* p = kbase + ((long long)rs[kc] * Tmax + kc) * (2 * d);
+      kd[u] = Chunk<T>::raw(p);
+      vd[u] = Chunk<T>::raw(p + d);
     }
   };
-  float kb[U][EPL], vb[U][EPL];
-  if (pos > 0) {
-    fetch(0, 0, kb);
-    fetch(0, d, vb);  // the first batch of values travels during the scores and the softmax
+  uint4 kb[U], vb[U];
+  if (pos > 0) fetch(0, kb, vb);
+  float qc[EPL], acc[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    qc[e] = qs[sub * EPL + e];
+    acc[e] = grp == 0 ? vs[sub * EPL + e] : 0.f;  // the new position (probability 1 relative to the running maximum, its own score)
   }
-  // ---- scores of the history ----
+  float m = sc_wave_sum(q * kn) * scale;  // the new position's own score (its key is still in registers)
+  float l = grp == 0 ? 1.f : 0.f;         // every lane of a group counts the group's keys: the wave sum below is LPK times the normaliser
+  // ---- the history, one batch at a time with a running maximum (the probabilities stay in the lanes that multiply the values) ----
   for (int k0 = 0; k0 < pos; k0 += KPB) {
-    float nx[U][EPL];
+    uint4 kx[U], vx[U];
     const bool more = k0 + KPB < pos;
-    if (more) fetch(k0 + KPB, 0, nx);
+    if (more) fetch(k0 + KPB, kx, vx);
+    float s[U], bm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int key = k0 + u * KPI + grp;
-      float part = 0.f;
+      float kv[EPL], part = 0.f;
+      Chunk<T>::unpack(kb[u], kv);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) part = fmaf(kb[u][e], qc[e], part);
-      part = group_sum<LPK>(part);
-      if (sub == LPK - 1 && key < pos) ss[key] = part * scale;
+      for (int e = 0; e < EPL; ++e) part = fmaf(kv[e], qc[e], part);
+      part = group_sum<LPK>(part) * scale;
+      s[u] = k0 + u * KPI + grp < pos ? part : -INFINITY;
+      bm = fmaxf(bm, s[u]);
+    }
+    const float mn = fmaxf(m, sc_wave_max(bm));
+    const float corr = __expf(m - mn);
+    m = mn;
+    l *= corr;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] *= corr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pk = __expf(s[u] - m);
+      float vv[EPL];
+      Chunk<T>::unpack(vb[u], vv);
+      l += pk;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, vv[e], acc[e]);
     }
     if (more) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) kb[u][e] = nx[u][e];
+      for (int u = 0; u < U; ++u) {
+        kb[u] = kx[u];
+        vb[u] = vx[u];
+      }
     }
   }
-  if (lane == 0) ss[pos] = s_new;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // ---- softmax over positions 0 .. pos ----
-  float m = -INFINITY;
-  for (int t = lane; t <= pos; t += 64) m = fmaxf(m, ss[t]);
-  m = sc_wave_max(m);
-  float l = 0.f;
-  for (int t = lane; t <= pos; t += 64) {
-    const float e = __expf(ss[t] - m);
-    ss[t] = e;
-    l += e;
-  }
-  l = sc_wave_sum(l);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // ---- context ----
-  float acc[EPL];
-#pragma unroll
-  for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-  for (int k0 = 0; k0 < pos; k0 += KPB) {
-    float nx[U][EPL];
-    const bool more = k0 + KPB < pos;
-    if (more) fetch(k0 + KPB, d, nx);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int key = k0 + u * KPI + grp;
-      const float pk = key < pos ? ss[key] : 0.f;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pk, vb[u][e], acc[e]);
-    }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) vb[u][e] = nx[u][e];
-    }
-  }
+  l = sc_wave_sum(l) * (1.f / LPK);
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   if (grp == 0) {
-    const float pn = ss[pos], inv = 1.f / l;
+    const float inv = 1.f / l;
     float o8[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) o8[e] = fmaf(pn, vs[sub * EPL + e], acc[e]) * inv;
+    for (int e = 0; e < EPL; ++e) o8[e] = acc[e] * inv;
     Chunk<T>::st(out + (long long)n * ldo + h * DH + sub * EPL, o8);
   }
 }
@@ -290,13 +286,13 @@ SC_API int sc_attention_decode(int dtype, const void* qkv, long long ldqkv, void
   SC_CHECK_ARG(dtype == 0 || dtype == 1, "sc_attention_decode: dtype must be 0 (f32) or 1 (bf16)");
   SC_CHECK_ARG(N >= 1 && H >= 1 && Tmax >= 1 && Tmax <= 512 && pos >= 0 && pos < Tmax, "sc_attention_decode: bad sizes N=%d H=%d Tmax=%d (<= 512) pos=%d",
                N, H, Tmax, pos);
-  SC_CHECK_ARG((long long)N * H <= 0x7fffffffLL, "sc_attention_decode: too many (row, head) pairs");
+  SC_CHECK_ARG((long long)(N + 15) * H <= 0x0fffffffLL, "sc_attention_decode: too many (row, head) pairs");
   const long long d = (long long)H * DH;
   SC_CHECK_ARG(ldqkv >= 3 * d && ldo >= d, "sc_attention_decode: row strides too small");
   SC_CHECK_ARG(((uintptr_t)cache | (uintptr_t)qkv) % 16 == 0 && ldqkv % 8 == 0, "sc_attention_decode: buffers must be 16-byte aligned");
   SC_CHECK_ARG(ldo % 8 == 0 && (uintptr_t)out % 16 == 0, "sc_attention_decode: the output must be 16-byte aligned with a row stride multiple of 8");
-  const dim3 grid((unsigned)sc_cdiv(N * H, 4));
-  const size_t smem = (size_t)4 * (2 * DH + 2 * Tmax) * sizeof(float);
+  const dim3 grid((unsigned)(sc_cdiv(sc_cdiv(N, 16) * H, 8) * 8 * 4));  // (chunks of 16 rows x heads) rounded up to the 8 XCDs, 4 workgroups each
+  const size_t smem = (size_t)4 * (2 * DH + Tmax) * sizeof(float);
   if (dtype == 0)
     hipLaunchKernelGGL(attn_decode_kernel<float>, grid, dim3(256), smem, stream, (const float*)qkv, ldqkv, (float*)cache, table, (float*)out, ldo,
                        N, H, Tmax, pos, scale);
