@@ -484,6 +484,143 @@ __global__ __launch_bounds__(256) void ctc_psi_fast_kernel(const float* x, const
   }
 }
 
+// The factorised scores of one sentence's 16 rows as an exact-f32 matrix product on the matrix cores: S (16 x V) = P (16 x T) E_b (T x V),
+// v_mfma_f32_16x16x4_f32 (a chain of f32 multiply-adds: the vector kernel's arithmetic, summed in another order).  grid (ceil(V / 256), N / 16),
+// 4 waves of 64 columns each.  A lane reads 16 bytes of a frame's row of E -- 4 columns, one for each of its wave's 4 accumulator tiles, so
+// tile j holds columns c0 + 4 (lane & 15) + j and a row of the result leaves as 16-byte stores -- and one value of P^T (T x 16, LDS) per 4
+// frames.  The variant of P for a row's own last token (r_blank instead of r_sum) differs in ONE column per row: a wave whose 64 columns hold
+// such a token runs a second set of accumulators on the same loads.  Frames past the sentence's length have E = 0 for every token but the
+// blank, whose column is overwritten: the sweep stops at the length.  phi is kept only as P: the rare exact form re-reads r_prev.
+__global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const float* E, const float* bmax, const int* enc_lens,
+                                                           const int* eos_frame, const float* r_prev, const long long* last, float* psi, int N,
+                                                           int T, int V, int beam, int plen, int blank, int eos) {
+  extern __shared__ __attribute__((aligned(16))) float s_all[];  // P^T [2][T][16] (r_sum, r_blank variants), a[2][16], partial maxima [8][32]
+  float* s_P0 = s_all;
+  float* s_P1 = s_all + 16 * T;
+  float* s_a = s_all + 32 * T;
+  float* s_red = s_a + 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.y * 16, b = n0 / beam;
+  const int start = plen > 1 ? plen : 1;
+  for (int i = tid; i < 16 * T; i += 256) {
+    const int t = i >> 4, r = i & 15;
+    const float r0 = r_prev[((long long)t * 2 + 0) * N + n0 + r], r1 = r_prev[((long long)t * 2 + 1) * N + n0 + r];
+    s_P0[i] = logaddexpf(r0, r1);
+    s_P1[i] = r1;
+  }
+  __syncthreads();
+  {  // a = max over the frames t - 1 = start - 1 .. T - 2 of each of the 32 (variant, row) columns
+    const int col = tid & 31, part = tid >> 5;
+    const float* src = (col < 16 ? s_P0 : s_P1) + (col & 15);
+    float mx = -INFINITY;
+    for (int t = start - 1 + part; t < T - 1; t += 8) mx = fmaxf(mx, src[t * 16]);
+    s_red[part * 32 + col] = mx;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float mx = s_red[tid];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) mx = fmaxf(mx, s_red[q * 32 + tid]);
+    s_a[tid] = (mx == -INFINITY) ? 0.f : mx;
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * T; i += 256) s_all[i] = __expf(s_all[i] - s_a[(i >= 16 * T ? 16 : 0) + (i & 15)]);
+  __syncthreads();
+  const int c0 = blockIdx.x * 256 + w * 64;
+  if (c0 >= V) return;
+  const int rr = lane & 15, kq = lane >> 4;
+  const int cl = c0 + 4 * rr;  // this lane's 4 columns (V % 4 == 0: all inside or all outside)
+  const bool col_ok = cl < V;
+  const int len = enc_lens[b];
+  const int tend = min(T, len);
+  const long long lc_lane = plen > 0 ? last[n0 + rr] : 0;
+  const bool dual = __any(lc_lane >= c0 && lc_lane < c0 + 64);
+  const float* Ec = E + (long long)b * T * V + cl;
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc0[j] = acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int UL = 8;  // k-steps (of 4 frames) whose loads are in flight together
+  for (int t0 = start; t0 < tend; t0 += 4 * UL) {
+    float4 e[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int t = t0 + 4 * u + kq;
+      e[u] = (t < tend && col_ok) ? *(const float4*)(Ec + (long long)t * V) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      if (t0 + 4 * u < tend) {  // (uniform)
+        const int ta = min(t0 + 4 * u + kq, tend) - 1;  // (frames past the end meet e = 0)
+        const float a0 = s_P0[ta * 16 + rr];
+        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].x, acc0[0], 0, 0, 0);
+        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].y, acc0[1], 0, 0, 0);
+        acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].z, acc0[2], 0, 0, 0);
+        acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].w, acc0[3], 0, 0, 0);
+        if (dual) {
+          const float a1 = s_P1[ta * 16 + rr];
+          acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].x, acc1[0], 0, 0, 0);
+          acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].y, acc1[1], 0, 0, 0);
+          acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].z, acc1[2], 0, 0, 0);
+          acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].w, acc1[3], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!col_ok) return;
+  // ---- epilogue: lane = columns cl .. cl + 3 (tile j = column cl + j) of rows 4 kq + v ----
+  const float4 bc4 = *(const float4*)(bmax + (long long)b * V + cl);
+  const float bc[4] = {bc4.x, bc4.y, bc4.z, bc4.w};
+  const float* xc = x + (long long)b * T * V + cl;
+  float first[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float pad_x = (cl + j == blank) ? 0.f : CTC_IMPOSSIBLE;
+    first[j] = (plen == 0) ? ((0 < len) ? xc[j] : pad_x) : CTC_IMPOSSIBLE;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int row = 4 * kq + v, n = n0 + row;
+    const long long lastc = plen > 0 ? last[n] : 0;  // (the reference takes token 0 for the empty prefix, ctc_decoding.py:84)
+    const float a0r = s_a[row], a1r = s_a[16 + row];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cl + j;
+      const bool sel = (c == lastc);
+      const float a = sel ? a1r : a0r;
+      float S = sel ? acc1[j][v] : acc0[j][v];
+      const float f0 = first[j] - a - bc[j];  // (the empty prefix's first term is not scaled by phi: it may tower over a + bmax[c])
+      const bool exact = f0 > 80.f;
+      S += exact ? 0.f : __expf(f0);
+      float out;
+      if (S > 1e-30f && !exact) {
+        out = a + bc[j] + __logf(S);
+      } else {  // underflow (or an impossible row): the exact two-sweep form for this (row, candidate)
+        const float pad_x = (c == blank) ? 0.f : CTC_IMPOSSIBLE;
+        const float* rp = r_prev + n;
+        float m = first[j];
+        for (int t = start; t < T; ++t) {
+          const float r0 = rp[((long long)(t - 1) * 2 + 0) * N], r1 = rp[((long long)(t - 1) * 2 + 1) * N];
+          m = fmaxf(m, (sel ? r1 : logaddexpf(r0, r1)) + ((t < len) ? xc[(long long)t * V + j] : pad_x));
+        }
+        float sum = __expf(first[j] - m);
+        for (int t = start; t < T; ++t) {
+          const float r0 = rp[((long long)(t - 1) * 2 + 0) * N], r1 = rp[((long long)(t - 1) * 2 + 1) * N];
+          sum += __expf((sel ? r1 : logaddexpf(r0, r1)) + ((t < len) ? xc[(long long)t * V + j] : pad_x) - m);
+        }
+        out = m + __logf(sum);
+      }
+      if (c == eos) {
+        const long long ef = eos_frame[n];
+        out = logaddexpf(r_prev[(ef * 2 + 0) * N + n], r_prev[(ef * 2 + 1) * N + n]);
+      }
+      if (c == blank) out = CTC_IMPOSSIBLE;
+      o[j] = out;
+    }
+    *(float4*)(psi + (long long)n * V + cl) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // An affine map r -> logaddexp(a + r, b) in the log domain (R -> A R + B in the probability domain), and "g after f".
 struct LogAffine {
   float a, b;
@@ -601,6 +738,16 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 2 && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
                    (long long)B * beam <= 65535, "sc_ctc_prefix_scores_fast: bad sizes B=%d beam=%d T=%d V=%d plen=%d", B, beam, T, V, plen);
   const int N = B * beam;
+  // Whole beams of 16 rows: the matrix-core form (SC_CTC_PSI_MFMA=0: the vector kernel below).
+  static const bool use_mfma = [] { const char* e = getenv("SC_CTC_PSI_MFMA"); return !(e && e[0] == '0'); }();
+  const size_t smem_m = ((size_t)32 * T + 32 + 256) * sizeof(float);
+  if (use_mfma && beam % 16 == 0 && V % 4 == 0 && smem_m <= 64 * 1024 &&
+      (((uintptr_t)E | (uintptr_t)bmax | (uintptr_t)psi) % 16) == 0) {
+    hipLaunchKernelGGL(ctc_psi_mfma_kernel, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame, r_prev,
+                       last, psi, N, T, V, beam, plen, blank, eos);
+    SC_LAUNCH_CHECK("ctc_psi_mfma_kernel");
+    return SC_OK;
+  }
   // (16 rows per workgroup when the beam allows: the (B, T, V) factor is then read once per sentence and step)
   int rpb = beam % 16 == 0 ? 16 : beam % 8 == 0 ? 8 : beam % 4 == 0 ? 4 : beam % 2 == 0 ? 2 : 1;
   while (rpb > 1 && (size_t)rpb * (4 * T + 2) * sizeof(float) > 64 * 1024) rpb >>= 1;

@@ -395,14 +395,16 @@ def test_replayed_decoding_follows_parameter_updates():
         Fn.weights.invalidate()
 
 
+@pytest.mark.parametrize("beam", [8, 16, 32])
 @pytest.mark.parametrize("plen", [0, 1, 3, 9])
-def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen):
+def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen, beam):
     """sc_ctc_prefix_scores_fast (exp(phi + x) = exp(phi - a) exp(x - bmax), the second factor made once per batch) against the exact
     two-sweep kernel on peaky log-probabilities with ragged lengths, impossible rows and forward variables far apart: every score within
-    2e-4 absolute + 2e-6 relative, <eos> / blank columns identical."""
+    2e-4 absolute + 2e-6 relative, <eos> / blank columns identical.  Beams of 16 rows take the matrix-core kernel (ctc_psi_mfma_kernel:
+    the same sums as f32 MFMA products, 16 rows of a sentence per tile), other beams the vector kernel."""
     from speechain_amd import functional as Fn
 
-    B, beam, T, V, blank, eos = 3, 8, 61, 300, 0, 299
+    B, T, V, blank, eos = 3, 61, 300, 0, 299
     gen = torch.Generator().manual_seed(40 + plen)
     logits = torch.randn(B, T, V, generator=gen) * 6.0  # peaky: log-probabilities from about -0.01 down to -50
     x = torch.log_softmax(logits, dim=-1).cuda()
