@@ -502,11 +502,55 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n0 = blockIdx.y * 16, b = n0 / beam;
   const int start = plen > 1 ? plen : 1;
-  for (int i = tid; i < 16 * T; i += 256) {
-    const int t = i >> 4, r = i & 15;
-    const float r0 = r_prev[((long long)t * 2 + 0) * N + n0 + r], r1 = r_prev[((long long)t * 2 + 1) * N + n0 + r];
-    s_P0[i] = logaddexpf(r0, r1);
-    s_P1[i] = r1;
+  // the first frames of E are on their way while the workgroup prepares P (they depend on nothing in LDS)
+  const int c0 = blockIdx.x * 256 + w * 64;
+  const int rr = lane & 15, kq = lane >> 4;
+  const int cl = c0 + 4 * rr;  // this lane's 4 columns (V % 4 == 0: all inside or all outside)
+  const bool col_ok = cl < V;
+  const int len = enc_lens[b];
+  const int tend = min(T, len);
+  // Every load is unconditional (the compiler then counts them: waits of the form vmcnt(n), not vmcnt(0)): frames past the end re-read the
+  // last frame and meet a zero of P, columns past the vocabulary re-read its last four and are never stored.
+  const float* Ec = E + (long long)b * T * V + min(cl, V - 4);
+  constexpr int UL = 4, D = 4;  // batches of UL k-steps (4 frames each); D batches in flight per wave (16 KB)
+  auto fetch = [&](int t0, float4 (&e)[UL]) {
+#pragma unroll
+    for (int u = 0; u < UL; ++u) e[u] = *(const float4*)(Ec + (long long)max(min(t0 + 4 * u + kq, tend - 1), 0) * V);
+  };
+  // phi of the 16 rows: 8 pairs of r_prev per thread and pass.  The first pass's loads go out BEFORE the first D batches of E, so that its
+  // arithmetic waits for them only (loads retire in order) while E travels.
+  float4 ring[D][UL];
+  auto phi_load = [&](int i0, float (&r0)[8], float (&r1)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = min(i0 + 256 * q, 16 * T - 1);
+      r0[q] = r_prev[((long long)(i >> 4) * 2 + 0) * N + n0 + (i & 15)];
+      r1[q] = r_prev[((long long)(i >> 4) * 2 + 1) * N + n0 + (i & 15)];
+    }
+  };
+  auto phi_store = [&](int i0, const float (&r0)[8], const float (&r1)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + 256 * q;
+      if (i < 16 * T) {
+        s_P0[i] = logaddexpf(r0[q], r1[q]);
+        s_P1[i] = r1[q];
+      }
+    }
+  };
+  {
+    float r0[8], r1[8];
+    phi_load(tid, r0, r1);
+    asm volatile("" ::: "memory");  // (keeps the two groups of loads in this order)
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) fetch(start + dd * 4 * UL, ring[dd]);
+    asm volatile("" ::: "memory");
+    phi_store(tid, r0, r1);
+  }
+  for (int i0 = tid + 256 * 8; i0 < 16 * T; i0 += 256 * 8) {
+    float r0[8], r1[8];
+    phi_load(i0, r0, r1);
+    phi_store(i0, r0, r1);
   }
   __syncthreads();
   {  // a = max over the frames t - 1 = start - 1 .. T - 2 of each of the 32 (variant, row) columns
@@ -526,45 +570,47 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
   __syncthreads();
   for (int i = tid; i < 32 * T; i += 256) s_all[i] = __expf(s_all[i] - s_a[(i >= 16 * T ? 16 : 0) + (i & 15)]);
   __syncthreads();
-  const int c0 = blockIdx.x * 256 + w * 64;
   if (c0 >= V) return;
-  const int rr = lane & 15, kq = lane >> 4;
-  const int cl = c0 + 4 * rr;  // this lane's 4 columns (V % 4 == 0: all inside or all outside)
-  const bool col_ok = cl < V;
-  const int len = enc_lens[b];
-  const int tend = min(T, len);
   const long long lc_lane = plen > 0 ? last[n0 + rr] : 0;
   const bool dual = __any(lc_lane >= c0 && lc_lane < c0 + 64);
-  const float* Ec = E + (long long)b * T * V + cl;
   f32x4 acc0[4], acc1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc0[j] = acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  constexpr int UL = 8;  // k-steps (of 4 frames) whose loads are in flight together
-  for (int t0 = start; t0 < tend; t0 += 4 * UL) {
-    float4 e[UL];
+  auto consume = [&](const float4 (&eb)[UL], int tb) {
 #pragma unroll
     for (int u = 0; u < UL; ++u) {
-      const int t = t0 + 4 * u + kq;
-      e[u] = (t < tend && col_ok) ? *(const float4*)(Ec + (long long)t * V) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < UL; ++u) {
-      if (t0 + 4 * u < tend) {  // (uniform)
-        const int ta = min(t0 + 4 * u + kq, tend) - 1;  // (frames past the end meet e = 0)
-        const float a0 = s_P0[ta * 16 + rr];
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].x, acc0[0], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].y, acc0[1], 0, 0, 0);
-        acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].z, acc0[2], 0, 0, 0);
-        acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e[u].w, acc0[3], 0, 0, 0);
-        if (dual) {
-          const float a1 = s_P1[ta * 16 + rr];
-          acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].x, acc1[0], 0, 0, 0);
-          acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].y, acc1[1], 0, 0, 0);
-          acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].z, acc1[2], 0, 0, 0);
-          acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e[u].w, acc1[3], 0, 0, 0);
-        }
+      const int t = tb + 4 * u + kq;
+      const int ta = min(t, tend) - 1;
+      const float a0 = t < tend ? s_P0[ta * 16 + rr] : 0.f;
+      const float4 e = eb[u];
+      acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e.x, acc0[0], 0, 0, 0);
+      acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e.y, acc0[1], 0, 0, 0);
+      acc0[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e.z, acc0[2], 0, 0, 0);
+      acc0[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, e.w, acc0[3], 0, 0, 0);
+      if (dual) {
+        const float a1 = t < tend ? s_P1[ta * 16 + rr] : 0.f;
+        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e.x, acc1[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e.y, acc1[1], 0, 0, 0);
+        acc1[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e.z, acc1[2], 0, 0, 0);
+        acc1[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, e.w, acc1[3], 0, 0, 0);
       }
     }
+  };
+  // Rounds of D batches.  While another round follows, every slot is refilled right after it is consumed, with no condition around the
+  // loads (conditional loads make the compiler wait for vmcnt(0)); the last round only consumes.
+  constexpr int R = 4 * UL * D;
+  int t0 = start;
+  {
+    for (; t0 + R < tend; t0 += R) {
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        consume(ring[dd], t0 + dd * 4 * UL);
+        fetch(t0 + R + dd * 4 * UL, ring[dd]);
+      }
+    }
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd)
+      if (t0 + dd * 4 * UL < tend) consume(ring[dd], t0 + dd * 4 * UL);  // (uniform)
   }
   if (!col_ok) return;
   // ---- epilogue: lane = columns cl .. cl + 3 (tile j = column cl + j) of rows 4 kq + v ----
