@@ -913,7 +913,15 @@ __device__ __forceinline__ void topk_rows_body(const float* row, int L, int K, f
         }
       }
     }
-    if (run) atomicAdd(&hist[cur], run);
+    {  // scores of one row share their exponent: in the first round a whole wave usually holds ONE bin -- one atomic for the wave then
+      const int c0 = __builtin_amdgcn_readfirstlane(cur);
+      if (__all(run == 0 || cur == c0)) {
+        const unsigned tot = (unsigned)sc_wave_sum((float)run);  // (< 2^24: exact)
+        if ((tid & 63) == 0 && tot) atomicAdd(&hist[c0], tot);
+      } else if (run) {
+        atomicAdd(&hist[cur], run);
+      }
+    }
     __syncthreads();
     topk_find_bin(hist, nb, need, &sh_bin, &sh_above);
     __syncthreads();
@@ -1277,7 +1285,7 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(const T* logits, l
 
 // beam_candidates_kernel and the row's own top K (topk_rows_body) in one launch: the candidate row lives in LDS only -- the (N, V) score
 // matrix (10 MB at N = 512, V = 5000) is never written, and the selection's four sweeps read LDS instead of L2.  1024 threads per row.
-template <typename T>
+template <typename T, int PER>
 __global__ __launch_bounds__(1024) void beam_candidates_topk_kernel(const T* logits, long long ld, const float* psi, const float* psi_prev,
                                                                    const float* beam_score, float* eos_score, float* other_max, int V,
                                                                    float inv_temp, float w, int blank, int eos, int K, float* vals,
@@ -1286,8 +1294,21 @@ __global__ __launch_bounds__(1024) void beam_candidates_topk_kernel(const T* log
   __shared__ float red[32];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const T* row = logits + (long long)n * ld;
+  // the row's logits and prefix scores: PER of each per thread, all loads in flight at once (the three sweeps below read registers)
+  float x[PER], ps[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int v = min(tid + 1024 * u, V - 1);
+    x[u] = Elem<T>::ld(row + v) * inv_temp;
+  }
+  if (psi) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) ps[u] = psi[(long long)n * V + min(tid + 1024 * u, V - 1)];
+  }
   float m = -INFINITY;
-  for (int v = tid; v < V; v += 1024) m = fmaxf(m, Elem<T>::ld(row + v) * inv_temp);
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (tid + 1024 * u < V) m = fmaxf(m, x[u]);
   m = sc_wave_max(m);
   if (lane == 0) red[wv] = m;
   __syncthreads();
@@ -1295,7 +1316,9 @@ __global__ __launch_bounds__(1024) void beam_candidates_topk_kernel(const T* log
 #pragma unroll
   for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
   float s = 0.f;
-  for (int v = tid; v < V; v += 1024) s += __expf(Elem<T>::ld(row + v) * inv_temp - m);
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (tid + 1024 * u < V) s += __expf(x[u] - m);
   s = sc_wave_sum(s);
   if (lane == 0) red[16 + wv] = s;
   __syncthreads();
@@ -1306,17 +1329,21 @@ __global__ __launch_bounds__(1024) void beam_candidates_topk_kernel(const T* log
   const float bs = beam_score[n];
   const float pp = (psi && psi_prev) ? psi_prev[n] : 0.f;
   float best_other = -INFINITY;
-  for (int v = tid; v < V; v += 1024) {
-    float t = Elem<T>::ld(row + v) * inv_temp - lse;
-    if (psi) {
-      if (v == blank) t = CTC_IMPOSSIBLE;
-      t = (1.f - w) * t + w * (psi[(long long)n * V + v] - pp);
-    }
-    candrow[v] = t + bs;
-    if (v == eos) {
-      if (eos_score) eos_score[n] = t;
-    } else {
-      best_other = fmaxf(best_other, t);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int v = tid + 1024 * u;
+    if (v < V) {
+      float t = x[u] - lse;
+      if (psi) {
+        if (v == blank) t = CTC_IMPOSSIBLE;
+        t = (1.f - w) * t + w * (ps[u] - pp);
+      }
+      candrow[v] = t + bs;
+      if (v == eos) {
+        if (eos_score) eos_score[n] = t;
+      } else {
+        best_other = fmaxf(best_other, t);
+      }
     }
   }
   __syncthreads();
@@ -1348,12 +1375,18 @@ SC_API int sc_beam_candidates_topk(int dtype, const void* logits, long long ld, 
                    K >= 1 && K <= 64 && K <= V,
                "sc_beam_candidates_topk: bad sizes N=%d V=%d K=%d (V <= 12288, K <= 64)", N, V, K);
   const size_t smem = (size_t)V * sizeof(float);
-  if (dtype == 0)
-    hipLaunchKernelGGL(beam_candidates_topk_kernel<float>, dim3(N), dim3(1024), smem, stream, (const float*)logits, ld, psi, psi_prev, beam_score,
-                       eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos, K, vals, idx);
-  else
-    hipLaunchKernelGGL(beam_candidates_topk_kernel<unsigned short>, dim3(N), dim3(1024), smem, stream, (const unsigned short*)logits, ld, psi,
-                       psi_prev, beam_score, eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos, K, vals, idx);
+#define SC_LAUNCH_CT(T, PER)                                                                                                            \
+  hipLaunchKernelGGL((beam_candidates_topk_kernel<T, PER>), dim3(N), dim3(1024), smem, stream, (const T*)logits, ld, psi, psi_prev, beam_score, \
+                     eos_score, other_max, V, 1.f / temperature, ctc_weight, blank, eos, K, vals, idx)
+  // (elements per thread: 6 covers V <= 6144, 12 the LDS limit)
+  if (dtype == 0) {
+    if (V <= 6144) SC_LAUNCH_CT(float, 6);
+    else SC_LAUNCH_CT(float, 12);
+  } else {
+    if (V <= 6144) SC_LAUNCH_CT(unsigned short, 6);
+    else SC_LAUNCH_CT(unsigned short, 12);
+  }
+#undef SC_LAUNCH_CT
   SC_LAUNCH_CHECK("beam_candidates_topk_kernel");
   return SC_OK;
 }

@@ -158,7 +158,7 @@ def test_two_stage_topk_equals_one_selection(G, parts, L, K):
     assert torch.equal(i2, i1)
 
 
-@pytest.mark.parametrize("R,L,K", [(32, 80000, 32), (3, 92, 8), (5, 5000, 64), (2, 40, 40), (4, 1025, 2)])
+@pytest.mark.parametrize("R,L,K", [(32, 80000, 32), (3, 92, 8), (5, 5000, 64), (2, 40, 40), (4, 1025, 2), (6, 9000, 16), (3, 12288, 32), (4, 5000, 1)])
 def test_topk_rows_against_torch(R, L, K):
     """sc_topk_rows: values equal torch.topk's (sorted, descending); indices point at those values; among equal values the lower index
     comes first and wins the last place (rows with many ties, -inf runs and the reference's -1e20 included)."""
