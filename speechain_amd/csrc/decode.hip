@@ -491,9 +491,11 @@ __global__ __launch_bounds__(256) void ctc_psi_fast_kernel(const float* x, const
 // frames.  The variant of P for a row's own last token (r_blank instead of r_sum) differs in ONE column per row: a wave whose 64 columns hold
 // such a token runs a second set of accumulators on the same loads.  Frames past the sentence's length have E = 0 for every token but the
 // blank, whose column is overwritten: the sweep stops at the length.  phi is kept only as P: the rare exact form re-reads r_prev.
+template <bool PREP>
 __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const float* E, const float* bmax, const int* enc_lens,
                                                            const int* eos_frame, const float* r_prev, const long long* last, float* psi, int N,
-                                                           int T, int V, int beam, int plen, int blank, int eos) {
+                                                           int T, int V, int beam, int plen, int blank, int eos, const float* pt,
+                                                           const float* pa) {
   extern __shared__ __attribute__((aligned(16))) float s_all[];  // P^T [2][T][16] (r_sum, r_blank variants), a[2][16], partial maxima [8][32]
   float* s_P0 = s_all;
   float* s_P1 = s_all + 16 * T;
@@ -538,6 +540,21 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
       }
     }
   };
+  if constexpr (PREP) {  // P^T and a of this group of 16 rows, made by ctc_state_kernel with the rows themselves: a copy instead of the block below
+    const f32x4* src = (const f32x4*)(pt + (long long)blockIdx.y * 32 * T);
+    f32x4* dst = (f32x4*)s_all;
+    f32x4 pv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pv[q] = src[min(tid + 256 * q, 8 * T - 1)];
+    asm volatile("" ::: "memory");  // (keeps the two groups of loads in this order)
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) fetch(start + dd * 4 * UL, ring[dd]);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[min(tid + 256 * q, 8 * T - 1)] = pv[q];  // (past the end: the last element once more)
+    for (int i = tid + 256 * 8; i < 8 * T; i += 256) dst[i] = src[i];
+    if (tid < 32) s_a[tid] = pa[(long long)blockIdx.y * 32 + tid];
+  } else {
   {
     float r0[8], r1[8];
     phi_load(tid, r0, r1);
@@ -569,6 +586,7 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
   }
   __syncthreads();
   for (int i = tid; i < 32 * T; i += 256) s_all[i] = __expf(s_all[i] - s_a[(i >= 16 * T ? 16 : 0) + (i & 15)]);
+  }
   __syncthreads();
   if (c0 >= V) return;
   const long long lc_lane = plen > 0 ? last[n0 + rr] : 0;
@@ -705,7 +723,8 @@ __device__ __forceinline__ void la_wave_scan(const float* a, const float* b, flo
 // wave scans replace the T sequential steps (measured: 282 us per launch with one lane walking the frames).
 __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const int* enc_lens, const float* r_prev, const long long* last,
                                                        const long long* beam_idx, const long long* tokens, float* r_new, int N, int T, int V,
-                                                       int beam, int plen, int blank, const float* psi_prev, float* psi_sel) {
+                                                       int beam, int plen, int blank, const float* psi_prev, float* psi_sel, float* pt,
+                                                       float* pa) {
   extern __shared__ float s_st[];  // [4 waves][4][T]: a (x label), b (x label + phi), then r^n; x blank
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + w;
@@ -746,6 +765,35 @@ __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const in
     r_new[((long long)t * 2 + 0) * N + n] = rn[t];
     r_new[((long long)t * 2 + 1) * N + n] = t < start ? CTC_IMPOSSIBLE : sa[t];
   }
+  if (pt) {
+    // What ctc_psi_mfma_kernel derives from this row at the NEXT position (prefix length plen + 1), made here once instead of in every
+    // one of its workgroups: phi (r_sum, r_blank), a = its maximum over the frames the sums read, P = exp(phi - a) in the kernel's P^T layout.
+    const int g = n >> 4, r = n & 15;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (int t = lane; t < T; t += 64) {  // (every lane reads back its own frames only)
+      const float rb = t < start ? CTC_IMPOSSIBLE : sa[t];
+      const float p0 = logaddexpf(rn[t], rb);
+      sb[t] = p0;
+      xb[t] = rb;
+      if (t >= plen && t < T - 1) {
+        m0 = fmaxf(m0, p0);
+        m1 = fmaxf(m1, rb);
+      }
+    }
+    m0 = sc_wave_max(m0);
+    m1 = sc_wave_max(m1);
+    const float a0 = (m0 == -INFINITY) ? 0.f : m0, a1 = (m1 == -INFINITY) ? 0.f : m1;
+    float* p0 = pt + ((long long)(g * 2 + 0) * T) * 16 + r;
+    float* p1 = pt + ((long long)(g * 2 + 1) * T) * 16 + r;
+    for (int t = lane; t < T; t += 64) {
+      p0[(long long)t * 16] = __expf(sb[t] - a0);
+      p1[(long long)t * 16] = __expf(xb[t] - a1);
+    }
+    if (lane == 0) {
+      pa[g * 32 + r] = a0;
+      pa[g * 32 + 16 + r] = a1;
+    }
+  }
 }
 
 }  // namespace
@@ -779,8 +827,10 @@ SC_API int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* 
 // batch by the caller (two torch launches).  Results equal sc_ctc_prefix_scores' up to the f32 rounding of a 250-term sum.
 SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float* bmax, const int* enc_lens, const int* eos_frame,
                                      const float* r_prev, const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank,
-                                     int eos, hipStream_t stream) {
+                                     int eos, const float* pt, const float* pa, hipStream_t stream) {
   SC_CHECK_ARG(x && E && bmax && enc_lens && eos_frame && r_prev && psi && (last || plen == 0), "sc_ctc_prefix_scores_fast: null pointer");
+  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || (plen >= 1 && beam % 16 == 0 && (uintptr_t)pt % 16 == 0)),
+               "sc_ctc_prefix_scores_fast: pt / pa come together, from sc_ctc_prefix_state at prefix length plen - 1, beam %% 16 == 0");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 2 && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
                    (long long)B * beam <= 65535, "sc_ctc_prefix_scores_fast: bad sizes B=%d beam=%d T=%d V=%d plen=%d", B, beam, T, V, plen);
   const int N = B * beam;
@@ -789,8 +839,12 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
   const size_t smem_m = ((size_t)32 * T + 32 + 256) * sizeof(float);
   if (use_mfma && beam % 16 == 0 && V % 4 == 0 && smem_m <= 64 * 1024 &&
       (((uintptr_t)E | (uintptr_t)bmax | (uintptr_t)psi) % 16) == 0) {
-    hipLaunchKernelGGL(ctc_psi_mfma_kernel, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame, r_prev,
-                       last, psi, N, T, V, beam, plen, blank, eos);
+    if (pt)
+      hipLaunchKernelGGL(ctc_psi_mfma_kernel<true>, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
+                         r_prev, last, psi, N, T, V, beam, plen, blank, eos, pt, pa);
+    else
+      hipLaunchKernelGGL(ctc_psi_mfma_kernel<false>, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
+                         r_prev, last, psi, N, T, V, beam, plen, blank, eos, pt, pa);
     SC_LAUNCH_CHECK("ctc_psi_mfma_kernel");
     return SC_OK;
   }
@@ -817,15 +871,16 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
 // (what ctc_decoding.py:162-196 gathers out of its (T, 2, N, V) tensor).
 SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
                                const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, const float* psi_prev,
-                               float* psi_sel, hipStream_t stream) {
+                               float* psi_sel, float* pt, float* pa, hipStream_t stream) {
   SC_CHECK_ARG(x && enc_lens && r_prev && beam_idx && tokens && r_new && (last || plen == 0), "sc_ctc_prefix_state: null pointer");
   SC_CHECK_ARG((psi_prev == nullptr) == (psi_sel == nullptr), "sc_ctc_prefix_state: psi_prev and psi_sel come together");
   SC_CHECK_ARG(r_prev != r_new, "sc_ctc_prefix_state: r_prev and r_new must be two buffers");
+  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || beam % 16 == 0), "sc_ctc_prefix_state: pt / pa come together and want beam %% 16 == 0");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && V >= 1 && plen >= 0 && blank >= 0 && blank < V, "sc_ctc_prefix_state: bad sizes");
   const size_t smem = (size_t)4 * 4 * T * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_ctc_prefix_state: T too large for the LDS rows (%d frames)", T);
   hipLaunchKernelGGL(ctc_state_kernel, dim3(sc_cdiv(B * beam, 4)), dim3(256), smem, stream, x, enc_lens, r_prev, last, beam_idx, tokens, r_new,
-                     B * beam, T, V, beam, plen, blank, psi_prev, psi_sel);
+                     B * beam, T, V, beam, plen, blank, psi_prev, psi_sel, pt, pa);
   SC_LAUNCH_CHECK("ctc_state_kernel");
   return SC_OK;
 }

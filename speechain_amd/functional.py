@@ -2127,8 +2127,18 @@ def ctc_prefix_factors(x: torch.Tensor):
     return torch.exp(x - bmax[:, None, :]).contiguous(), bmax
 
 
-def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None, factors=None) -> torch.Tensor:
-    """psi (N, V) of every candidate token of every hypothesis row (sc_ctc_prefix_scores); r_prev None = the empty prefix."""
+def ctc_prefix_prepared(B: int, beam: int, T: int, device):
+    """Buffers (pt, pa) that `ctc_prefix_state(..., prepared=)` fills and the next position's `ctc_prefix_scores(..., prepared=)` reads:
+    P = exp(phi - a) of the rows in the matrix-core kernel's layout, (N / 16, 2, T, 16), and a, (N / 16, 2, 16).  beam % 16 == 0."""
+    assert beam % 16 == 0
+    G = B * beam // 16
+    return torch.empty(G, 2, T, 16, dtype=torch.float32, device=device), torch.empty(G, 2, 16, dtype=torch.float32, device=device)
+
+
+def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None, factors=None,
+                      prepared=None) -> torch.Tensor:
+    """psi (N, V) of every candidate token of every hypothesis row (sc_ctc_prefix_scores); r_prev None = the empty prefix.  `prepared`:
+    the (pt, pa) pair that `ctc_prefix_state` filled when it made r_prev (with `factors` only; plen >= 1)."""
     require_gpu(x, "ctc_prefix_scores")
     B, T, V = x.shape
     if r_prev is None:
@@ -2137,23 +2147,29 @@ def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int
     if factors is not None and T >= 2:
         E, bmax = factors
         assert E.shape == x.shape and E.is_contiguous() and bmax.shape == (B, V) and bmax.is_contiguous()
+        pt, pa = prepared if (prepared is not None and plen >= 1) else (None, None)
+        if pt is not None:
+            assert pt.shape == (B * beam // 16, 2, T, 16) and pt.is_contiguous() and pa.shape == (B * beam // 16, 2, 16) and pa.is_contiguous()
         lib.call("sc_ctc_prefix_scores_fast", _p(x), _p(E), _p(bmax), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B,
-                 beam, T, V, int(plen), int(blank), int(eos), stream())
+                 beam, T, V, int(plen), int(blank), int(eos), _p(pt), _p(pa), stream())
         return psi
     lib.call("sc_ctc_prefix_scores", _p(x), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B, beam, T, V, int(plen),
              int(blank), int(eos), stream())
     return psi
 
 
-def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int, out=None, psi_prev=None, psi_sel=None) -> torch.Tensor:
-    """Forward variables (T, 2, N) of the rows that continue row beam_idx[n] with tokens[n] (sc_ctc_prefix_state)."""
+def ctc_prefix_state(x, enc_lens, r_prev, last, plen: int, beam_idx, tokens, beam: int, blank: int, out=None, psi_prev=None, psi_sel=None,
+                     prepared=None) -> torch.Tensor:
+    """Forward variables (T, 2, N) of the rows that continue row beam_idx[n] with tokens[n] (sc_ctc_prefix_state).  `prepared`: a
+    (pt, pa) pair of `ctc_prefix_prepared` to fill for the next position's `ctc_prefix_scores`."""
     B, T, V = x.shape
     if r_prev is None:
         r_prev = ctc_prefix_init(x, enc_lens, beam, blank)
     r_new = out if out is not None else torch.empty(T, 2, B * beam, dtype=torch.float32, device=x.device)
     # (psi_prev (N, V) / psi_sel (N): the same launch also gathers psi_sel[n] = psi_prev[beam_idx[n], tokens[n]], ctc_decoding.py:63)
     lib.call("sc_ctc_prefix_state", _p(x), _p(enc_lens), _p(r_prev.contiguous()), _p(last), _p(beam_idx.contiguous()), _p(tokens), _p(r_new),
-             B, beam, T, V, int(plen), int(blank), _p(psi_prev), _p(psi_sel), stream())
+             B, beam, T, V, int(plen), int(blank), _p(psi_prev), _p(psi_sel), _p(prepared[0] if prepared is not None else None),
+             _p(prepared[1] if prepared is not None else None), stream())
     return r_new
 
 

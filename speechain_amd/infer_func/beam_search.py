@@ -36,6 +36,7 @@ from speechain_amd.infer_func.ctc_decoding import CTCPrefixScorer
 _CTC_BRANCH = os.environ.get("SC_DECODE_CTC_BRANCH", "0") == "1"
 _FUSED_TAIL = os.environ.get("SC_DECODE_FUSED_TAIL", "1") == "1"  # (A/B knob: 0 = candidate matrix in HBM, separate top-k launches)
 _CTC_PSI_FAST = os.environ.get("SC_CTC_PSI_FAST", "1") == "1"  # (A/B knob: 0 = one v_exp per (row, token, frame))
+_CTC_PSI_PREPARED = os.environ.get("SC_CTC_PSI_PREPARED", "1") == "1"  # (A/B knob: 0 = every score workgroup derives exp(phi - a) from r itself)
 
 eps = 1e-20
 minus_inf = -1e20
@@ -112,6 +113,9 @@ class _Session:
             # factors of the prefix scores' exponential, made once per batch in begin() (Fn.ctc_prefix_factors, into these static buffers)
             self.E = torch.empty(B, T, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
             self.bmax = torch.empty(B, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
+            # P = exp(phi - a) of the rows, written by the state launch of a position for the score launch of the next (whole beams of 16)
+            self.prep = (Fn.ctc_prefix_prepared(B, beam, T, dev)
+                         if (self.E is not None and beam % 16 == 0 and V % 4 == 0 and T >= 2 and _CTC_PSI_PREPARED) else None)
         self.cache, self.graphs, self.pool, self.calls = None, {}, None, 0
         self.use_graphs = os.environ.get("SC_DECODE_NO_GRAPH", "0") != "1"
 
@@ -145,10 +149,11 @@ class _Session:
                 with (side if side is not None else contextlib.nullcontext()):
                     if pos > 0:
                         Fn.ctc_prefix_state(self.x, self.enc_lens, self.r[pos & 1 ^ 1], self.prev_tokens, pos - 1, self.beam_idx, self.tokens, beam,
-                                            self.pad, out=self.r[pos & 1], psi_prev=self.psi[pos & 1 ^ 1], psi_sel=self.psi_sel)
+                                            self.pad, out=self.r[pos & 1], psi_prev=self.psi[pos & 1 ^ 1], psi_sel=self.psi_sel, prepared=self.prep)
                     psi = Fn.ctc_prefix_scores(self.x, self.enc_lens, self.eos_frame, self.r[pos & 1], self.tokens if pos > 0 else None, pos,
                                                beam, self.pad, self.sos_eos, out=self.psi[pos & 1],
-                                               factors=(self.E, self.bmax) if self.E is not None else None)
+                                               factors=(self.E, self.bmax) if self.E is not None else None,
+                                               prepared=self.prep if pos > 0 else None)
             self.cache.pos = pos
             logits = self.fn.forward_step(self.tokens, self.cache, self.beam_idx if pos > 0 else None)
             if side is not None:

@@ -395,6 +395,36 @@ def test_replayed_decoding_follows_parameter_updates():
         Fn.weights.invalidate()
 
 
+@pytest.mark.parametrize("beam,plen", [(16, 0), (16, 1), (32, 4), (16, 9)])
+def test_prefix_scores_from_the_state_launch_s_prepared_factors(beam, plen):
+    """sc_ctc_prefix_state with pt / pa (exp(phi - a) and a of the new rows, in the matrix-core kernel's layout) + sc_ctc_prefix_scores_fast
+    reading them: bit-identical scores to the launch that derives them from r itself (ragged lengths, an impossible row, a row whose
+    forward variables are all impossible)."""
+    from speechain_amd import functional as Fn
+
+    B, T, V, blank, eos = 3, 61, 300, 0, 299
+    gen = torch.Generator().manual_seed(90 + plen)
+    x = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 5.0, dim=-1).cuda()
+    enc_lens = torch.tensor([T, 47, 30], dtype=torch.int32).cuda()
+    N = B * beam
+    eos_frame = (enc_lens.repeat_interleave(beam) - 1).to(torch.int32)
+    r = torch.randn(T, 2, N, generator=gen) * 20.0 - 30.0
+    r[: max(plen - 1, 0)] = -1e20
+    r[:, :, 5] = -1e20
+    r = r.cuda()
+    last = torch.randint(1, V - 1, (N,), generator=gen).cuda()
+    beam_idx = (torch.arange(N) // beam * beam + torch.randint(0, beam, (N,), generator=gen)).cuda()
+    tokens = torch.randint(1, V - 1, (N,), generator=gen).cuda()
+    prep = Fn.ctc_prefix_prepared(B, beam, T, x.device)
+    r_new = Fn.ctc_prefix_state(x, enc_lens, r, last if plen > 0 else None, plen, beam_idx, tokens, beam, blank, prepared=prep)
+    r_ref = Fn.ctc_prefix_state(x, enc_lens, r, last if plen > 0 else None, plen, beam_idx, tokens, beam, blank)
+    assert torch.equal(r_new, r_ref)
+    fac = Fn.ctc_prefix_factors(x)
+    want = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r_new, tokens, plen + 1, beam, blank, eos, factors=fac)
+    got = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r_new, tokens, plen + 1, beam, blank, eos, factors=fac, prepared=prep)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 @pytest.mark.parametrize("beam", [8, 16, 32])
 @pytest.mark.parametrize("plen", [0, 1, 3, 9])
 def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen, beam):
