@@ -689,7 +689,16 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
 struct LogAffine {
   float a, b;
 };
-__device__ __forceinline__ LogAffine la_then(const LogAffine f, const LogAffine g) { return {f.a + g.a, logaddexpf(g.a + f.b, g.b)}; }
+// logaddexp on the hardware exponential and logarithm (v_exp_f32 / v_log_f32: ~1 ulp each).  log1pf's polynomial (~150 instructions with
+// two divisions) buys RELATIVE accuracy of log(1 + e) for tiny e; the sum m + log(1 + e) is rounded to ulp(m) anyway, so for forward
+// variables (log-probabilities, |m| from ~1e-3 up to 1e20) the absolute error of this form, <= ~1.2e-7, is below the rounding of the exact
+// one.  The scans below are chains of ~30 DEPENDENT logaddexps per row at one wave per SIMD: instruction count is their whole cost.
+__device__ __forceinline__ float logaddexp_hw(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return m;
+  return m + __logf(1.f + __expf(fminf(a, b) - m));
+}
+__device__ __forceinline__ LogAffine la_then(const LogAffine f, const LogAffine g) { return {f.a + g.a, logaddexp_hw(g.a + f.b, g.b)}; }
 
 // Inclusive scan over frames t = start .. T - 1 of the maps (a[t], b[t]) applied to r0, one wave: out[t] = (f_t o ... o f_start)(r0).
 // Lane l owns the CH consecutive frames start + l CH ...; a / b are read from LDS, the result is written over `out` (LDS).
@@ -709,14 +718,14 @@ __device__ __forceinline__ void la_wave_scan(const float* a, const float* b, flo
   }
   LogAffine pre = {__shfl_up(inc.a, 1, 64), __shfl_up(inc.b, 1, 64)};
   if (lane == 0) pre = {0.f, -INFINITY};
-  float r = logaddexpf(pre.a + r0, pre.b);  // the value just before this lane's first frame
+  float r = logaddexp_hw(pre.a + r0, pre.b);  // the value just before this lane's first frame
   for (int t = t0; t < t1; ++t) {
-    r = logaddexpf(a[t] + r, b[t]);
+    r = logaddexp_hw(a[t] + r, b[t]);
     out[t] = r;
   }
 }
 
-// grid (ceil(N / 4)); one wave per new row n: the forward variables of (parent row beam_idx[n]) + (token tokens[n]) over all frames.
+// One wave per new row n (2 or 4 per workgroup): the forward variables of (parent row beam_idx[n]) + (token tokens[n]) over all frames.
 // The two-line recursion (:132-142) is a pair of first-order linear recurrences in the probability domain,
 //   R^n_t = x_t (R^n_{t-1} + Phi_{t-1}),   R^b_t = xb_t (R^b_{t-1} + R^n_{t-1}),
 // so each is a prefix scan of affine maps: the lanes gather phi / x of the whole utterance into LDS (independent loads), then two
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const in
                                                        float* pa) {
   extern __shared__ float s_st[];  // [4 waves][4][T]: a (x label), b (x label + phi), then r^n; x blank
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n = blockIdx.x * 4 + w;
+  const int n = blockIdx.x * (blockDim.x >> 6) + w;
   if (n >= N) return;
   float* sa = s_st + (w * 4 + 0) * T;
   float* sb = s_st + (w * 4 + 1) * T;
@@ -740,16 +749,28 @@ __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const in
   const long long lastc = plen > 0 ? last[par] : 0;
   const float* xc = x + (long long)b * T * V;
   const int start = plen > 1 ? plen : 1;
-  for (int t = lane; t < T; t += 64) {
-    const float xl = (t < len) ? xc[(long long)t * V + c] : (c == blank ? 0.f : CTC_IMPOSSIBLE);
-    float phi = CTC_IMPOSSIBLE;
-    if (t >= 1) {
-      const float p0 = r_prev[((long long)(t - 1) * 2 + 0) * N + par], p1 = r_prev[((long long)(t - 1) * 2 + 1) * N + par];
-      phi = (c == lastc) ? p1 : logaddexpf(p0, p1);
+  for (int t0 = lane; t0 < T; t0 += 64 * 4) {  // (four frames per lane and pass: their 16 gathers -- one cache line per lane each -- fly together)
+    float xl[4], xk[4], p0[4], p1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(t0 + 64 * u, T - 1), tp = max(t - 1, 0);
+      xl[u] = xc[(long long)min(t, max(len - 1, 0)) * V + c];
+      xk[u] = xc[(long long)min(t, max(len - 1, 0)) * V + blank];
+      p0[u] = r_prev[((long long)tp * 2 + 0) * N + par];
+      p1[u] = r_prev[((long long)tp * 2 + 1) * N + par];
     }
-    sa[t] = xl;
-    sb[t] = xl + phi;  // b_t = x_t + phi_{t-1}
-    xb[t] = (t < len) ? xc[(long long)t * V + blank] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 64 * u;
+      if (t < T) {
+        const float xv = (t < len) ? xl[u] : (c == blank ? 0.f : CTC_IMPOSSIBLE);
+        float phi = CTC_IMPOSSIBLE;
+        if (t >= 1) phi = (c == lastc) ? p1[u] : logaddexpf(p0[u], p1[u]);
+        sa[t] = xv;
+        sb[t] = xv + phi;  // b_t = x_t + phi_{t-1}
+        xb[t] = (t < len) ? xk[u] : 0.f;
+      }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes, then its own reads)
   const float rn0 = (plen == 0) ? sa[0] : CTC_IMPOSSIBLE;  // r^n at frame start - 1 (:116-117); r^b there is impossible
@@ -877,9 +898,11 @@ SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float*
   SC_CHECK_ARG(r_prev != r_new, "sc_ctc_prefix_state: r_prev and r_new must be two buffers");
   SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || beam % 16 == 0), "sc_ctc_prefix_state: pt / pa come together and want beam %% 16 == 0");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && V >= 1 && plen >= 0 && blank >= 0 && blank < V, "sc_ctc_prefix_state: bad sizes");
-  const size_t smem = (size_t)4 * 4 * T * sizeof(float);
+  // (the rows' gathers -- one cache line per lane -- queue in their CU's address unit: two rows per workgroup spread 512 rows over all CUs)
+  const int wpb = (B * beam <= 1024) ? 2 : 4;
+  const size_t smem = (size_t)wpb * 4 * T * sizeof(float);
   SC_CHECK_ARG(smem <= 64 * 1024, "sc_ctc_prefix_state: T too large for the LDS rows (%d frames)", T);
-  hipLaunchKernelGGL(ctc_state_kernel, dim3(sc_cdiv(B * beam, 4)), dim3(256), smem, stream, x, enc_lens, r_prev, last, beam_idx, tokens, r_new,
+  hipLaunchKernelGGL(ctc_state_kernel, dim3(sc_cdiv(B * beam, wpb)), dim3(64 * wpb), smem, stream, x, enc_lens, r_prev, last, beam_idx, tokens, r_new,
                      B * beam, T, V, beam, plen, blank, psi_prev, psi_sel, pt, pa);
   SC_LAUNCH_CHECK("ctc_state_kernel");
   return SC_OK;
