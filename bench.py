@@ -762,8 +762,8 @@ class ASRDecodeWorkload:
         return self.last
 
     def roofline(self):
-        """The CTC prefix-score kernel: per launch it reads the (B, T, V) f32 log-probabilities once per beam row group (L2 serves the
-        15 other beams of a sentence) and writes psi (N, V); exp-bound rather than byte-bound at these sizes -- both figures are given."""
+        """The CTC prefix-score kernel: per launch it reads the (B, T, V) f32 factor tensor E once (the 16 beams of a sentence are one
+        matrix-core tile of rows) and writes psi (N, V): byte-bound -- the multiply-add rate is given beside it."""
         fast = self.kernel_ms.get("sc_ctc_prefix_scores_fast", (0, 0.0))[0] > 0  # (the factorised form: the default)
         n, ms = self.kernel_ms["sc_ctc_prefix_scores_fast" if fast else "sc_ctc_prefix_scores"]
         per = ms / max(n, 1)
@@ -771,7 +771,9 @@ class ASRDecodeWorkload:
         alg = BATCH * T * V * 4 + N * V * 4 + T * 2 * N * 4
         achieved = alg / (per * 1e-3) / 1e9
         rate = N * V * (T - 1) / (per * 1e-3) / 1e12
-        return {"bound": "hbm", "kernel": "ctc_psi_fast_kernel" if fast else "ctc_psi_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        mfma = fast and DECODE_CONF["beam_size"] % 16 == 0 and V % 4 == 0  # (whole beams of 16 rows: exact-f32 matrix-core products)
+        return {"bound": "hbm", "kernel": "ctc_psi_mfma_kernel" if mfma else "ctc_psi_fast_kernel" if fast else "ctc_psi_kernel",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
                 "note": (f"{rate:.2f} T multiply-adds/s: one per (row, token, frame), the exponential's second factor made once per batch; "
                          if fast else f"{rate:.2f} T exp/s: one v_exp per (row, token, frame); ") + "launches per batch "
