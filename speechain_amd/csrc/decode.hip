@@ -925,31 +925,34 @@ __device__ __forceinline__ unsigned topk_key(float v) {
 }
 
 // finds, scanning bins from the top, the bin in which the running count reaches `need`; returns it and the count above it
-__device__ __forceinline__ void topk_find_bin(const unsigned* hist, int nbins, unsigned need, int* sh_bin, unsigned* sh_above) {
-  // one wave: lane l owns bins [nbins - (l + 1) per, nbins - l per) from the top
-  const int lane = threadIdx.x;
-  if (lane < 64) {
-    const int per = nbins / 64;
-    unsigned mine = 0;
-    for (int i = 0; i < per; ++i) mine += hist[nbins - 1 - (lane * per + i)];
-    unsigned inc = mine;
+// The bin in which the running count from the TOP reaches `need`, by all 1024 threads: thread t owns bins nbins - 1 - t per - i (per = 1
+// or 2); wave scans, the waves' totals through wtot[16], one barrier inside.  (One wave walking 32 bins per lane read the histogram with a
+// 64-way bank conflict: ~1.2 us per round, three rounds per selection.)
+__device__ __forceinline__ void topk_find_bin(const unsigned* hist, int nbins, unsigned need, int* sh_bin, unsigned* sh_above, unsigned* wtot) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per = nbins >> 10;  // (nbins is 2048 or 1024, the workgroup 1024 threads)
+  const int b0 = nbins - 1 - tid * per;
+  const unsigned h0 = hist[b0], h1 = per == 2 ? hist[b0 - 1] : 0u;
+  const unsigned mine = h0 + h1;
+  unsigned inc = mine;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned up = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += up;
-    }
-    const unsigned before = inc - mine;  // count in the bins above this lane's
-    if (before < need && inc >= need) {  // the crossing is in this lane's bins
-      unsigned run = before;
-      for (int i = 0; i < per; ++i) {
-        const int b = nbins - 1 - (lane * per + i);
-        if (run + hist[b] >= need) {
-          *sh_bin = b;
-          *sh_above = run;
-          break;
-        }
-        run += hist[b];
-      }
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  unsigned base = 0;
+  for (int i = 0; i < w; ++i) base += wtot[i];
+  inc += base;
+  const unsigned before = inc - mine;  // count in the bins above this thread's
+  if (before < need && inc >= need) {  // the crossing is in this thread's bins
+    if (before + h0 >= need) {
+      *sh_bin = b0;
+      *sh_above = before;
+    } else {
+      *sh_bin = b0 - 1;
+      *sh_above = before + h0;
     }
   }
 }
@@ -1001,12 +1004,11 @@ __device__ __forceinline__ void topk_rows_body(const float* row, int L, int K, f
       }
     }
     __syncthreads();
-    topk_find_bin(hist, nb, need, &sh_bin, &sh_above);
+    topk_find_bin(hist, nb, need, &sh_bin, &sh_above, sel_key);  // (sel_key is free until the collection pass)
     __syncthreads();
     prefix |= (unsigned)sh_bin << shifts[rd];
     mask_hi |= (unsigned)(nb - 1) << shifts[rd];
-    need -= sh_above;
-    __syncthreads();
+    need -= sh_above;  // (no barrier here: sh_bin / sh_above are next written two barriers on, the histogram is read by nobody any more)
   }
   const unsigned thr = prefix;  // the K-th largest key; `need` (>= 1) elements equal to it are wanted, lowest indices first
   if (tid == 0) {
@@ -1103,17 +1105,24 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* x, long lo
 __device__ __forceinline__ int merge_rank(const unsigned* key, int parts, int K, int p, int j) {
   const unsigned k = key[p * K + j];
   int rank = j;
-  for (int q = 0; q < parts; ++q) {
-    if (q == p) continue;
-    const unsigned* kq = key + q * K;
-    int lo = 0, hi = K;
-    while (lo < hi) {  // first position of part q that does NOT beat the candidate (equal keys of an earlier part do beat it)
-      const int mid = (lo + hi) >> 1;
-      const bool beats = q < p ? kq[mid] >= k : kq[mid] > k;
-      lo = beats ? mid + 1 : lo;
-      hi = beats ? hi : mid;
+  int top = 1;
+  while (top * 2 <= K) top *= 2;  // largest power of two <= K
+  // Per other part q: how many of its (descending) keys beat the candidate -- equal keys of an earlier part do.  Branch-free searches, four
+  // parts abreast: the chains of dependent LDS reads of different parts overlap (15 parts x 6 reads one after the other took ~3 us).
+  for (int q0 = 0; q0 < parts; q0 += 4) {
+    int lo[4] = {0, 0, 0, 0};
+    for (int s = top; s > 0; s >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(q0 + u, parts - 1);
+        const int m = lo[u] + s;
+        const unsigned kv = key[q * K + min(m, K) - 1];
+        const bool beats = q < p ? kv >= k : kv > k;
+        lo[u] = (m <= K && beats) ? m : lo[u];
+      }
     }
-    rank += lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rank += (q0 + u < parts && q0 + u != p) ? lo[u] : 0;
   }
   return rank;
 }
@@ -1142,16 +1151,25 @@ __global__ __launch_bounds__(1024) void topk_merge_advance_kernel(const float* v
   __shared__ unsigned key[1024];
   __shared__ float sv[64];
   __shared__ long long si[64];
+  __shared__ int sp[64], st[64];  // part (= parent beam) and token of the survivors, kept beside si so that nobody divides by L
   const int n = parts * K, tid = threadIdx.x, b = blockIdx.x, beam = parts;
   const long long base = (long long)b * n;
-  if (tid < n) key[tid] = topk_key(vals1[base + tid]);
+  float myv = 0.f;
+  long long tok = 0;
+  if (tid < n) {  // (value and index in one trip: the ranks below then touch LDS only)
+    myv = vals1[base + tid];
+    tok = idx1[base + tid];
+    key[tid] = topk_key(myv);
+  }
   if (tid < beam) prev_tokens[(long long)b * beam + tid] = tokens[(long long)b * beam + tid];
   __syncthreads();
   if (tid < n) {
     const int rank = merge_rank(key, parts, K, tid / K, tid % K);
     if (rank < K) {
-      sv[rank] = vals1[base + tid];
-      si[rank] = (long long)(tid / K) * L + idx1[base + tid];
+      sv[rank] = myv;
+      si[rank] = (long long)(tid / K) * L + tok;
+      sp[rank] = tid / K;
+      st[rank] = (int)tok;
     }
   }
   __syncthreads();
@@ -1168,17 +1186,16 @@ __global__ __launch_bounds__(1024) void topk_merge_advance_kernel(const float* v
     vals[(long long)b * K + tid] = sv[tid];
     idx[(long long)b * K + tid] = si[tid];
   }
-  if (tid == 0) {
-    int kept = 0;
-    for (int i = 0; i < K && kept < beam; ++i) {
-      const long long id = si[i];
-      const int tok = (int)(id % L);
-      if (tok == eos_token) continue;
-      const long long r = (long long)b * beam + kept;
-      scores[r] = sv[i];
+  if (tid < 64) {  // the next rows: the first `beam` survivors that are not <eos>, in order -- one wave, a ballot instead of a walk
+    const int tok = tid < K ? st[tid] : eos_token;
+    const bool keep = tok != eos_token;
+    const unsigned long long m = __ballot(keep);
+    const int at = __popcll(m & ((1ull << tid) - 1ull));
+    if (keep && at < beam) {
+      const long long r = (long long)b * beam + at;
+      scores[r] = sv[tid];
       tokens[r] = tok;
-      beam_idx[r] = (long long)b * beam + id / L;
-      ++kept;
+      beam_idx[r] = (long long)b * beam + sp[tid];
     }
   }
 }
