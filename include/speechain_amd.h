@@ -429,13 +429,15 @@ int sc_ctc_prefix_scores(const float* x, const int* enc_lens, const int* eos_fra
 /* The same scores with the exponential factorised (exp(phi + x) = exp(phi - a) * exp(x - bmax)): E (B, T, V) = exp(x - bmax) and bmax (B, V) =
  * max over the frames of x are made once per batch by the caller; a step is then one multiply-add per (row, token, frame) instead of
  * one v_exp.  Sums that underflow are redone exactly per (row, token): the result is sc_ctc_prefix_scores' up to f32 rounding of the sum.
- * Whole beams of 16 rows (beam % 16 == 0, V % 4 == 0) run as exact-f32 matrix-core products, 16 rows of a sentence per tile.
- * pt (N / 16, 2, T, 16) / pa (N / 16, 2, 16), both or neither: P = exp(phi - a) and a of the rows' r_sum / r_blank, as sc_ctc_prefix_state
- * wrote them at prefix length plen - 1 for THESE rows (r_prev is that call's r_new); NULL: derived from r_prev inside the launch (same bits). */
+ * With V % 4 == 0 the sums run as exact-f32 matrix-core products, up to 16 rows of a sentence per tile (G = ceil(beam / 16) groups per
+ * sentence; a beam of 16 fills its tile).
+ * pt (B G, 2, T, 16) / pa (B G, 2, 16), both or neither: P = exp(phi - a) and a of the rows' r_sum / r_blank, group by group, as
+ * sc_ctc_prefix_state wrote them at prefix length plen - 1 for THESE rows (r_prev is that call's r_new; rows a group does not hold are never
+ * read into a result); NULL: derived from r_prev inside the launch (same bits). */
 int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float* bmax, const int* enc_lens, const int* eos_frame, const float* r_prev,
                               const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank, int eos, const float* pt,
                               const float* pa, hipStream_t stream);
-/* (pt / pa, both or neither, beam % 16 == 0: see sc_ctc_prefix_scores_fast -- the next position's launch then copies them instead of
+/* (pt / pa, both or neither: see sc_ctc_prefix_scores_fast -- the next position's launch then copies them instead of
  *  deriving them in each of its workgroups) */
 int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float* r_prev, const long long* last, const long long* beam_idx,
                         const long long* tokens, float* r_new, int B, int beam, int T, int V, int plen, int blank, const float* psi_prev, float* psi_sel,

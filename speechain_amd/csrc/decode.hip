@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void ctc_psi_fast_kernel(const float* x, const
 }
 
 // The factorised scores of one sentence's 16 rows as an exact-f32 matrix product on the matrix cores: S (16 x V) = P (16 x T) E_b (T x V),
-// v_mfma_f32_16x16x4_f32 (a chain of f32 multiply-adds: the vector kernel's arithmetic, summed in another order).  grid (ceil(V / 256), N / 16),
+// v_mfma_f32_16x16x4_f32 (a chain of f32 multiply-adds: the vector kernel's arithmetic, summed in another order).  grid (ceil(V / 256), B ceil(beam / 16)),
 // 4 waves of 64 columns each.  A lane reads 16 bytes of a frame's row of E -- 4 columns, one for each of its wave's 4 accumulator tiles, so
 // tile j holds columns c0 + 4 (lane & 15) + j and a row of the result leaves as 16-byte stores -- and one value of P^T (T x 16, LDS) per 4
 // frames.  The variant of P for a row's own last token (r_blank instead of r_sum) differs in ONE column per row: a wave whose 64 columns hold
@@ -502,7 +502,10 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
   float* s_a = s_all + 32 * T;
   float* s_red = s_a + 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n0 = blockIdx.y * 16, b = n0 / beam;
+  // group blockIdx.y = rows 16 gi .. of sentence b (G = ceil(beam / 16) groups per sentence; the last one may hold fewer than 16 rows:
+  // its idle rows repeat row nrows - 1 in every load and are never stored)
+  const int G = (beam + 15) >> 4, b = blockIdx.y / G, gi = blockIdx.y - b * G;
+  const int n0 = b * beam + gi * 16, nrows = min(16, beam - gi * 16);
   const int start = plen > 1 ? plen : 1;
   // the first frames of E are on their way while the workgroup prepares P (they depend on nothing in LDS)
   const int c0 = blockIdx.x * 256 + w * 64;
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = min(i0 + 256 * q, 16 * T - 1);
-      r0[q] = r_prev[((long long)(i >> 4) * 2 + 0) * N + n0 + (i & 15)];
-      r1[q] = r_prev[((long long)(i >> 4) * 2 + 1) * N + n0 + (i & 15)];
+      r0[q] = r_prev[((long long)(i >> 4) * 2 + 0) * N + n0 + min(i & 15, nrows - 1)];
+      r1[q] = r_prev[((long long)(i >> 4) * 2 + 1) * N + n0 + min(i & 15, nrows - 1)];
     }
   };
   auto phi_store = [&](int i0, const float (&r0)[8], const float (&r1)[8]) {
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
   }
   __syncthreads();
   if (c0 >= V) return;
-  const long long lc_lane = plen > 0 ? last[n0 + rr] : 0;
+  const long long lc_lane = plen > 0 ? last[n0 + min(rr, nrows - 1)] : 0;
   const bool dual = __any(lc_lane >= c0 && lc_lane < c0 + 64);
   f32x4 acc0[4], acc1[4];
 #pragma unroll
@@ -644,6 +647,7 @@ __global__ __launch_bounds__(256) void ctc_psi_mfma_kernel(const float* x, const
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int row = 4 * kq + v, n = n0 + row;
+    if (row >= nrows) break;
     const long long lastc = plen > 0 ? last[n] : 0;  // (the reference takes token 0 for the empty prefix, ctc_decoding.py:84)
     const float a0r = s_a[row], a1r = s_a[16 + row];
     float o[4];
@@ -789,7 +793,8 @@ __global__ __launch_bounds__(256) void ctc_state_kernel(const float* x, const in
   if (pt) {
     // What ctc_psi_mfma_kernel derives from this row at the NEXT position (prefix length plen + 1), made here once instead of in every
     // one of its workgroups: phi (r_sum, r_blank), a = its maximum over the frames the sums read, P = exp(phi - a) in the kernel's P^T layout.
-    const int g = n >> 4, r = n & 15;
+    const int sb_ = n / beam, j = n - sb_ * beam;  // (groups of 16 rows never straddle two sentences)
+    const int g = sb_ * ((beam + 15) >> 4) + (j >> 4), r = j & 15;
     float m0 = -INFINITY, m1 = -INFINITY;
     for (int t = lane; t < T; t += 64) {  // (every lane reads back its own frames only)
       const float rb = t < start ? CTC_IMPOSSIBLE : sa[t];
@@ -850,21 +855,22 @@ SC_API int sc_ctc_prefix_scores_fast(const float* x, const float* E, const float
                                      const float* r_prev, const long long* last, float* psi, int B, int beam, int T, int V, int plen, int blank,
                                      int eos, const float* pt, const float* pa, hipStream_t stream) {
   SC_CHECK_ARG(x && E && bmax && enc_lens && eos_frame && r_prev && psi && (last || plen == 0), "sc_ctc_prefix_scores_fast: null pointer");
-  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || (plen >= 1 && beam % 16 == 0 && (uintptr_t)pt % 16 == 0)),
-               "sc_ctc_prefix_scores_fast: pt / pa come together, from sc_ctc_prefix_state at prefix length plen - 1, beam %% 16 == 0");
+  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || (plen >= 1 && (uintptr_t)pt % 16 == 0)),
+               "sc_ctc_prefix_scores_fast: pt / pa come together, from sc_ctc_prefix_state at prefix length plen - 1");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 2 && V >= 1 && plen >= 0 && blank >= 0 && blank < V && eos >= 0 && eos < V &&
                    (long long)B * beam <= 65535, "sc_ctc_prefix_scores_fast: bad sizes B=%d beam=%d T=%d V=%d plen=%d", B, beam, T, V, plen);
   const int N = B * beam;
-  // Whole beams of 16 rows: the matrix-core form (SC_CTC_PSI_MFMA=0: the vector kernel below).
+  // The matrix-core form, groups of up to 16 rows of a sentence (SC_CTC_PSI_MFMA=0: the vector kernel below).
   static const bool use_mfma = [] { const char* e = getenv("SC_CTC_PSI_MFMA"); return !(e && e[0] == '0'); }();
   const size_t smem_m = ((size_t)32 * T + 32 + 256) * sizeof(float);
-  if (use_mfma && beam % 16 == 0 && V % 4 == 0 && smem_m <= 64 * 1024 &&
+  const int groups = B * sc_cdiv(beam, 16);
+  if (use_mfma && V % 4 == 0 && smem_m <= 64 * 1024 && groups <= 65535 &&
       (((uintptr_t)E | (uintptr_t)bmax | (uintptr_t)psi) % 16) == 0) {
     if (pt)
-      hipLaunchKernelGGL(ctc_psi_mfma_kernel<true>, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
+      hipLaunchKernelGGL(ctc_psi_mfma_kernel<true>, dim3(sc_cdiv(V, 256), groups), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
                          r_prev, last, psi, N, T, V, beam, plen, blank, eos, pt, pa);
     else
-      hipLaunchKernelGGL(ctc_psi_mfma_kernel<false>, dim3(sc_cdiv(V, 256), N / 16), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
+      hipLaunchKernelGGL(ctc_psi_mfma_kernel<false>, dim3(sc_cdiv(V, 256), groups), dim3(256), smem_m, stream, x, E, bmax, enc_lens, eos_frame,
                          r_prev, last, psi, N, T, V, beam, plen, blank, eos, pt, pa);
     SC_LAUNCH_CHECK("ctc_psi_mfma_kernel");
     return SC_OK;
@@ -896,7 +902,7 @@ SC_API int sc_ctc_prefix_state(const float* x, const int* enc_lens, const float*
   SC_CHECK_ARG(x && enc_lens && r_prev && beam_idx && tokens && r_new && (last || plen == 0), "sc_ctc_prefix_state: null pointer");
   SC_CHECK_ARG((psi_prev == nullptr) == (psi_sel == nullptr), "sc_ctc_prefix_state: psi_prev and psi_sel come together");
   SC_CHECK_ARG(r_prev != r_new, "sc_ctc_prefix_state: r_prev and r_new must be two buffers");
-  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr) && (!pt || beam % 16 == 0), "sc_ctc_prefix_state: pt / pa come together and want beam %% 16 == 0");
+  SC_CHECK_ARG((pt == nullptr) == (pa == nullptr), "sc_ctc_prefix_state: pt / pa come together");
   SC_CHECK_ARG(B >= 1 && beam >= 1 && T >= 1 && V >= 1 && plen >= 0 && blank >= 0 && blank < V, "sc_ctc_prefix_state: bad sizes");
   // (the rows' gathers -- one cache line per lane -- queue in their CU's address unit: two rows per workgroup spread 512 rows over all CUs)
   const int wpb = (B * beam <= 1024) ? 2 : 4;

@@ -2129,10 +2129,10 @@ def ctc_prefix_factors(x: torch.Tensor):
 
 def ctc_prefix_prepared(B: int, beam: int, T: int, device):
     """Buffers (pt, pa) that `ctc_prefix_state(..., prepared=)` fills and the next position's `ctc_prefix_scores(..., prepared=)` reads:
-    P = exp(phi - a) of the rows in the matrix-core kernel's layout, (N / 16, 2, T, 16), and a, (N / 16, 2, 16).  beam % 16 == 0."""
-    assert beam % 16 == 0
-    G = B * beam // 16
-    return torch.empty(G, 2, T, 16, dtype=torch.float32, device=device), torch.empty(G, 2, 16, dtype=torch.float32, device=device)
+    P = exp(phi - a) of the rows in the matrix-core kernel's layout, (B G, 2, T, 16), and a, (B G, 2, 16), for the G = ceil(beam / 16)
+    groups of up to 16 rows of every sentence (zeros where a group holds fewer rows)."""
+    G = B * ((beam + 15) // 16)
+    return torch.zeros(G, 2, T, 16, dtype=torch.float32, device=device), torch.zeros(G, 2, 16, dtype=torch.float32, device=device)
 
 
 def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int, blank: int, eos: int, out=None, factors=None,
@@ -2149,7 +2149,8 @@ def ctc_prefix_scores(x, enc_lens, eos_frame, r_prev, last, plen: int, beam: int
         assert E.shape == x.shape and E.is_contiguous() and bmax.shape == (B, V) and bmax.is_contiguous()
         pt, pa = prepared if (prepared is not None and plen >= 1) else (None, None)
         if pt is not None:
-            assert pt.shape == (B * beam // 16, 2, T, 16) and pt.is_contiguous() and pa.shape == (B * beam // 16, 2, 16) and pa.is_contiguous()
+            G = B * ((beam + 15) // 16)
+            assert pt.shape == (G, 2, T, 16) and pt.is_contiguous() and pa.shape == (G, 2, 16) and pa.is_contiguous()
         lib.call("sc_ctc_prefix_scores_fast", _p(x), _p(E), _p(bmax), _p(enc_lens), _p(eos_frame), _p(r_prev.contiguous()), _p(last), _p(psi), B,
                  beam, T, V, int(plen), int(blank), int(eos), _p(pt), _p(pa), stream())
         return psi

@@ -113,9 +113,9 @@ class _Session:
             # factors of the prefix scores' exponential, made once per batch in begin() (Fn.ctc_prefix_factors, into these static buffers)
             self.E = torch.empty(B, T, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
             self.bmax = torch.empty(B, V, dtype=torch.float32, device=dev) if _CTC_PSI_FAST else None
-            # P = exp(phi - a) of the rows, written by the state launch of a position for the score launch of the next (whole beams of 16)
+            # P = exp(phi - a) of the rows, written by the state launch of a position for the score launch of the next
             self.prep = (Fn.ctc_prefix_prepared(B, beam, T, dev)
-                         if (self.E is not None and beam % 16 == 0 and V % 4 == 0 and T >= 2 and _CTC_PSI_PREPARED) else None)
+                         if (self.E is not None and V % 4 == 0 and T >= 2 and _CTC_PSI_PREPARED) else None)
         self.cache, self.graphs, self.pool, self.calls = None, {}, None, 0
         self.use_graphs = os.environ.get("SC_DECODE_NO_GRAPH", "0") != "1"
 

@@ -395,7 +395,7 @@ def test_replayed_decoding_follows_parameter_updates():
         Fn.weights.invalidate()
 
 
-@pytest.mark.parametrize("beam,plen", [(16, 0), (16, 1), (32, 4), (16, 9)])
+@pytest.mark.parametrize("beam,plen", [(16, 0), (16, 1), (32, 4), (16, 9), (8, 2), (5, 3), (20, 1)])
 def test_prefix_scores_from_the_state_launch_s_prepared_factors(beam, plen):
     """sc_ctc_prefix_state with pt / pa (exp(phi - a) and a of the new rows, in the matrix-core kernel's layout) + sc_ctc_prefix_scores_fast
     reading them: bit-identical scores to the launch that derives them from r itself (ragged lengths, an impossible row, a row whose
@@ -425,13 +425,36 @@ def test_prefix_scores_from_the_state_launch_s_prepared_factors(beam, plen):
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
-@pytest.mark.parametrize("beam", [8, 16, 32])
+@pytest.mark.parametrize("beam,plen", [(8, 0), (16, 3), (6, 5)])
+def test_factorised_scores_vector_kernel(beam, plen):
+    """V % 4 != 0 keeps sc_ctc_prefix_scores_fast on ctc_psi_fast_kernel (one candidate per lane): same bound against the exact kernel."""
+    from speechain_amd import functional as Fn
+
+    B, T, V, blank, eos = 2, 47, 203, 0, 202
+    gen = torch.Generator().manual_seed(7 + plen)
+    x = torch.log_softmax(torch.randn(B, T, V, generator=gen) * 6.0, dim=-1).cuda()
+    enc_lens = torch.tensor([T, 31], dtype=torch.int32).cuda()
+    N = B * beam
+    r = torch.randn(T, 2, N, generator=gen) * 30.0 - 40.0
+    r[: max(plen - 1, 0)] = -1e20
+    r[:, :, 1] = -1e20
+    r = r.cuda()
+    eos_frame = (enc_lens.repeat_interleave(beam) - 1).to(torch.int32)
+    last = torch.randint(1, V - 1, (N,), generator=gen).cuda()
+    want = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r, last if plen > 0 else None, plen, beam, blank, eos)
+    got = Fn.ctc_prefix_scores(x, enc_lens, eos_frame, r, last if plen > 0 else None, plen, beam, blank, eos, factors=Fn.ctc_prefix_factors(x))
+    assert torch.equal(got[:, blank], want[:, blank]) and torch.equal(got[:, eos], want[:, eos])
+    assert torch.allclose(got, want, atol=2e-4, rtol=2e-6), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("beam", [3, 8, 16, 20, 32])
 @pytest.mark.parametrize("plen", [0, 1, 3, 9])
 def test_factorised_ctc_prefix_scores_equal_the_exact_kernel(plen, beam):
     """sc_ctc_prefix_scores_fast (exp(phi + x) = exp(phi - a) exp(x - bmax), the second factor made once per batch) against the exact
     two-sweep kernel on peaky log-probabilities with ragged lengths, impossible rows and forward variables far apart: every score within
-    2e-4 absolute + 2e-6 relative, <eos> / blank columns identical.  Beams of 16 rows take the matrix-core kernel (ctc_psi_mfma_kernel:
-    the same sums as f32 MFMA products, 16 rows of a sentence per tile), other beams the vector kernel."""
+    2e-4 absolute + 2e-6 relative, <eos> / blank columns identical.  The factorised form is the matrix-core kernel (ctc_psi_mfma_kernel:
+    the same sums as f32 MFMA products, up to 16 rows of a sentence per tile -- partly filled tiles for beams 3, 8, 20); the vector
+    kernel (V % 4 != 0) is covered by `test_factorised_scores_vector_kernel`."""
     from speechain_amd import functional as Fn
 
     B, T, V, blank, eos = 3, 61, 300, 0, 299
