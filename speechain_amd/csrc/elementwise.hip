@@ -232,33 +232,100 @@ __global__ __launch_bounds__(256) void embedding_zero_kernel(float* dw, long lon
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <typename T>
+// LDS: the ids are staged in LDS first (N ints), eight loads per lane in flight -- the two scans below then cost LDS reads; read from global
+// memory they were chains of N / 64 dependent loads per scan (98 us for 2016 positions, all of it latency).
+template <typename T, bool LDS>
 __global__ __launch_bounds__(64) void embedding_bwd_kernel(const long long* ids, const T* dy, long long ld, int N, int D, long long padding_idx,
                                                            float* dw) {
+  extern __shared__ int s_ids[];
   const int i = blockIdx.x, lane = threadIdx.x;
-  const long long my = ids[i];
+  if (LDS) {
+    for (int j0 = 0; j0 < N; j0 += 64 * 8) {
+      long long v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ids[min(j0 + 64 * u + lane, N - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + 64 * u + lane < N) s_ids[j0 + 64 * u + lane] = (int)v[u];  // (ids lie in [0, V), V an int)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its own LDS writes, then its own reads)
+  }
+  auto id_at = [&](int j) -> long long { return LDS ? (long long)s_ids[j] : ids[j]; };
+  const long long my = LDS ? (long long)s_ids[i] : ids[i];
   if (my == padding_idx) return;
   for (int base = 0; base < i; base += 64) {
     const int j = base + lane;
-    if (__ballot(j < i && ids[j] == my)) return;  // an earlier position owns this row
+    if (__ballot(j < i && id_at(j) == my)) return;  // an earlier position owns this row
   }
-  for (int c0 = 0; c0 < D; c0 += 64 * 4) {  // 4 columns per lane and pass
-    const int c = c0 + lane * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // 2 x 4 columns per lane and pass (D <= 512: one pass).  An id that many positions hold -- <sos> leads every sentence -- makes its owner
+  // sum that many rows, one per sentence, i.e. one per 64-position chunk: the owner first lists ALL its rows (LDS scans), then loads them
+  // eight at a time; the additions stay in position order.  (Chunk by chunk that was a chain of 32 dependent row loads: 55-90 us.)
+  int* s_rows = s_ids + N;
+  int cnt = 0;
+  if (LDS) {
     for (int base = i; base < N; base += 64) {
       const int j = base + lane;
-      unsigned long long mask = __ballot(j < N && ids[j] == my);
-      while (mask) {
-        const int row = base + __builtin_ctzll(mask);
-        mask &= mask - 1;
+      const bool hit = j < N && s_ids[j] == (int)my;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) s_rows[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+      cnt += __popcll(mask);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  for (int c0 = 0; c0 < D; c0 += 64 * 8) {
+    const int c = c0 + lane * 4;
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto add_rows = [&](const int (&rows)[8], int nr) {
+      float v[8][2][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c + e < D) acc[e] += Io<T>::ld(dy, (long long)row * ld + c + e);
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cc = c + 256 * h + e;
+            v[u][h][e] = cc < D ? Io<T>::ld(dy, (long long)rows[u] * ld + cc) : 0.f;
+          }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < nr) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[h][e] += v[u][h][e];
+        }
+    };
+    if (LDS) {
+      for (int r0 = 0; r0 < cnt; r0 += 8) {
+        int rows[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rows[u] = s_rows[min(r0 + u, cnt - 1)];
+        add_rows(rows, min(8, cnt - r0));
+      }
+    } else {
+      for (int base = i; base < N; base += 64) {
+        const int j = base + lane;
+        unsigned long long mask = __ballot(j < N && ids[j] == my);
+        while (mask) {
+          int rows[8], nr = 0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (mask) {
+              rows[u] = base + __builtin_ctzll(mask);
+              mask &= mask - 1;
+              nr = u + 1;
+            } else {
+              rows[u] = rows[0];
+            }
+          add_rows(rows, nr);
+        }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (c + e < D) dw[my * D + c + e] = acc[e];
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + 256 * h + e < D) dw[my * D + c + 256 * h + e] = acc[h][e];
   }
 }
 
@@ -275,10 +342,18 @@ SC_API int sc_embedding_bwd(int dtype, const long long* ids, const void* dy, lon
   const long long n4 = (long long)V * D / 4;
   hipLaunchKernelGGL(embedding_zero_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, stream, dw, n4);
   SC_LAUNCH_CHECK("embedding_zero_kernel");
-  if (dtype == 0)
-    hipLaunchKernelGGL(embedding_bwd_kernel<float>, dim3(N), dim3(64), 0, stream, ids, (const float*)dy, ld, N, D, padding_idx, dw);
-  else
-    hipLaunchKernelGGL(embedding_bwd_kernel<unsigned short>, dim3(N), dim3(64), 0, stream, ids, (const unsigned short*)dy, ld, N, D, padding_idx, dw);
+  const bool lds = N <= 7680;  // (60 KB: the ids and the owner's row list)
+  const size_t smem = lds ? (size_t)2 * N * sizeof(int) : 0;
+#define SC_LAUNCH_EMB(T, L) \
+  hipLaunchKernelGGL((embedding_bwd_kernel<T, L>), dim3(N), dim3(64), smem, stream, ids, (const T*)dy, ld, N, D, padding_idx, dw)
+  if (dtype == 0) {
+    if (lds) SC_LAUNCH_EMB(float, true);
+    else SC_LAUNCH_EMB(float, false);
+  } else {
+    if (lds) SC_LAUNCH_EMB(unsigned short, true);
+    else SC_LAUNCH_EMB(unsigned short, false);
+  }
+#undef SC_LAUNCH_EMB
   SC_LAUNCH_CHECK("embedding_bwd_kernel");
   return SC_OK;
 }

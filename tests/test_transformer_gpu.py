@@ -639,10 +639,11 @@ def test_attention_backward_through_the_c_abi(Tq, Tk, causal):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_embedding_table_gradient_vs_torch(dtype):
     """sc_embedding_bwd (one wave per position, the first holder of an id sums its rows in position order) against nn.Embedding's
-    autograd: repeated ids, the padding id, ids that never occur, D not a multiple of the 256-column pass."""
+    autograd: repeated ids, the padding id, ids that never occur, D not a multiple of the 256-column pass, an id held by a whole row of
+    positions (the owner lists its rows in LDS and loads them eight at a time)."""
     from speechain_amd import functional as Fn
     gen = torch.Generator().manual_seed(5)
-    for V, D, B, L in ((5000, 512, 32, 63), (37, 100, 3, 70), (9, 8, 2, 5)):
+    for V, D, B, L in ((5000, 512, 32, 63), (37, 100, 3, 70), (9, 8, 2, 5), (50, 24, 4, 2000)):  # (the last: N > 7680, ids read from global memory)
         table = torch.nn.Parameter(torch.randn(V, D, generator=gen).cuda())
         ids = torch.randint(0, V, (B, L), generator=gen)
         ids[0, :4] = 0           # padding id
