@@ -104,13 +104,20 @@ class Conv2dPrenet(Module):
             feat = torch.nn.functional.pad(feat, (int(d / 2), d - int(d / 2)))
 
         x, len_max = feat, feat.size(1)
+        # The blocks' length maps len -> floor((len - k) / s) + 1 = floor((len + s - k) / s) compose into ONE floor((len + C) / S)
+        # (floor(floor((x + C) / S) + c) / s) = floor((x + C + S c) / (S s)) for integers): two tiny launches per forward instead of three
+        # per block, each a ~5 us node on the captured step's only stream.
+        len_c, len_s = 0, 1
         for n, blk in enumerate(self.plan):
             bn = self.conv[blk["bn"]] if blk["bn"] is not None else None
             slope = self.conv[blk["bn"] + 1 if bn is not None else blk["conv"] + 1].negative_slope if blk["act"] == "LeakyReLU" else 0.0
             x = Fn.conv_block(x, self.conv[blk["conv"]], bn, blk["act"], slope, self.training, first=(n == 0))
             x = Fn.dropout(x, blk["p"], self.training)
-            feat_len = torch.div(feat_len - self.conv_kernel[0], self.conv_stride[0], rounding_mode="floor") + 1
+            len_c += len_s * (self.conv_stride[0] - self.conv_kernel[0])
+            len_s *= self.conv_stride[0]
             len_max = (len_max - self.conv_kernel[0]) // self.conv_stride[0] + 1
+        if self.plan:
+            feat_len = torch.div(feat_len + len_c, len_s, rounding_mode="floor")
         B, T, Fo, C = x.shape
         if len_max != T:  # (conv2d.py:266-271)
             raise RuntimeError(f"There is a bug in the {self.__class__.__name__}."
