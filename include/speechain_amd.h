@@ -494,6 +494,16 @@ int sc_ce_bwd(int dtype, const void* logits, const long long* target, const floa
 int sc_seq_loss_fwd(const float* rows, const long long* len, int B, int L, int length_normalized, float* loss, hipStream_t stream);
 int sc_seq_loss_bwd(const float* g, const long long* len, int B, int L, int length_normalized, float* grow, hipStream_t stream);
 
+/* LeastError (speechain/criterion/least_error.py:96-129): masked L1 / L2 / L1+L2 of pred (B, T, D) f32 / bf16 against tgt (B, T, D) f32
+ * over the frames t < len[b] (int64): loss (1) f32 = sum_valid mean_d f(pred - tgt) / (number of valid frames when `normalized`, else B).
+ * workspace: sc_least_error_workspace() bytes.  _bwd: dpred (B, T, D) in pred's dtype for an upstream scalar g (device), zero past the
+ * lengths.  dtype 0 = f32, 1 = bf16; loss_type 1 = L1, 2 = L2, 3 = L1 + L2. */
+long long sc_least_error_workspace(void);
+int sc_least_error_fwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
+                       void* workspace, float* loss, hipStream_t stream);
+int sc_least_error_bwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
+                       const float* g, void* dpred, hipStream_t stream);
+
 /* lse[r] = logsumexp_v logits[r][v] */
 int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream);
 

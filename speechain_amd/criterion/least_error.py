@@ -1,8 +1,9 @@
 """``LeastError``, drop-in for ``speechain.criterion.least_error.LeastError`` (speechain/criterion/least_error.py:15-129): masked L1 / L2 /
 L1+L2 between predicted and target feature tracks, normalised by the number of valid frames (or summed per utterance and averaged).
-(B, T)-sized bookkeeping on top of elementwise device arithmetic; predictions in bf16 are widened to float32 first."""
+On the GPU one fused reduction (``sc_least_error_fwd`` / ``_bwd``); the elementwise form below serves the CPU, ``update_range`` and targets with a gradient."""
 import torch
 
+from speechain_amd import functional as Fn
 from speechain_amd.criterion.abs import Criterion
 from speechain_amd.utilbox.train_util import make_mask_from_len
 
@@ -29,6 +30,11 @@ class LeastError(Criterion):
             tgt = tgt.unsqueeze(-1)
         elif tgt.dim() != 3:
             raise RuntimeError
+        # one fused reduction on the GPU (Fn.least_error: two launches forward, one backward); everything below is the reference's
+        # sequence of elementwise steps, kept for the CPU, for sliced feature ranges and for targets that carry a gradient
+        if (pred.is_cuda and self.update_range is None and pred.shape == tgt.shape and pred.is_contiguous() and not tgt.requires_grad
+                and pred.dtype in (torch.float32, torch.bfloat16)):
+            return Fn.least_error(pred, tgt, tgt_len, self.loss_type, self.is_normalized)
         pred, tgt = pred.float(), tgt.float()
         batch_size, feat_maxlen, feat_dim = pred.shape
         if self.update_range is not None:

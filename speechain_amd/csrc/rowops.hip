@@ -794,6 +794,80 @@ __global__ __launch_bounds__(256) void seq_loss_bwd_kernel(const float* g, const
   }
 }
 
+// Masked L1 / L2 / L1+L2 between two (B, T, D) tracks (speechain/criterion/least_error.py:96-129): sum over the valid frames t < len[b] of
+// mean_d f(pred - tgt), divided by the number of valid frames (normalised) or by B (per-utterance sums, batch mean).  The reference's
+// form is ~10 index- and frame-sized torch launches each way per term, and FastSpeech2 has five terms: 113 consecutive launches between
+// the forward and the backward pass of its step.  Here: partial sums per workgroup (f32 in a lane, double across lanes), a one-workgroup
+// finish in a fixed order, and one elementwise launch for the gradient.  loss_type: 1 = L1, 2 = L2, 3 = L1 + L2.
+template <typename T>
+struct LeIo;
+template <> struct LeIo<float> {
+  static __device__ __forceinline__ float ld(const float* p, long long i) { return p[i]; }
+  static __device__ __forceinline__ void st(float* p, long long i, float v) { p[i] = v; }
+};
+template <> struct LeIo<unsigned short> {
+  static __device__ __forceinline__ float ld(const unsigned short* p, long long i) { return sc_bf16_to_f32(p[i]); }
+  static __device__ __forceinline__ void st(unsigned short* p, long long i, float v) { p[i] = sc_f32_to_bf16(v); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void least_error_partial_kernel(const T* pred, const float* tgt, const long long* len, int B, int T_, int D,
+                                                                  int loss_type, double* partial) {
+  __shared__ double red[4];
+  const long long n = (long long)B * T_ * D, td = (long long)T_ * D;
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    const int b = (int)(i / td);
+    const int t = (int)((i - (long long)b * td) / D);
+    if (t < len[b]) {
+      const float d = LeIo<T>::ld(pred, i) - tgt[i];
+      acc += loss_type == 1 ? fabsf(d) : loss_type == 2 ? d * d : fabsf(d) + d * d;
+    }
+  }
+  const double w = (double)sc_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// denominator shared by both directions: D x (number of valid frames, or B)
+__device__ __forceinline__ double least_error_denominator(const long long* len, int B, int T_, int D, int normalized) {
+  if (!normalized) return (double)D * (double)B;
+  long long c = 0;
+  for (int b = 0; b < B; ++b) c += min((long long)T_, max(0LL, len[b]));
+  return (double)D * (double)c;
+}
+
+__global__ __launch_bounds__(64) void least_error_finish_kernel(const double* partial, int np, const long long* len, int B, int T_, int D,
+                                                                int normalized, float* loss) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < np; ++i) s += partial[i];
+    loss[0] = (float)(s / least_error_denominator(len, B, T_, D, normalized));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void least_error_bwd_kernel(const T* pred, const float* tgt, const long long* len, int B, int T_, int D,
+                                                              int loss_type, int normalized, const float* g, T* dpred) {
+  __shared__ float s_scale;
+  if (threadIdx.x == 0) s_scale = (float)((double)g[0] / least_error_denominator(len, B, T_, D, normalized));
+  __syncthreads();
+  const float scale = s_scale;
+  const long long n = (long long)B * T_ * D, td = (long long)T_ * D;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    const int b = (int)(i / td);
+    const int t = (int)((i - (long long)b * td) / D);
+    float v = 0.f;
+    if (t < len[b]) {
+      const float d = LeIo<T>::ld(pred, i) - tgt[i];
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // (torch: the gradient of |x| at 0 is 0)
+      v = scale * (loss_type == 1 ? sg : loss_type == 2 ? 2.f * d : sg + 2.f * d);
+    }
+    LeIo<T>::st(dpred, i, v);
+  }
+}
+
 }  // namespace
 
 #define SC_DISPATCH_TN(dtype, n, KERNEL, N0, N1, N2, ...)                                                  \
@@ -1041,3 +1115,40 @@ SC_API int sc_seq_loss_bwd(const float* g, const long long* len, int B, int L, i
   SC_LAUNCH_CHECK("seq_loss_bwd_kernel");
   return SC_OK;
 }
+
+// LeastError (speechain/criterion/least_error.py:96-129) of pred (B, T, D) f32 / bf16 against tgt (B, T, D) f32 over the frames t < len[b]:
+// loss (1) f32 = sum_valid mean_d f(pred - tgt) / (valid frames | B); workspace: sc_least_error_workspace() bytes.  _bwd: dpred (B, T, D) in
+// pred's dtype for an upstream scalar g (device), zero at the frames past the lengths.  dtype 0 = f32, 1 = bf16; loss_type 1 L1, 2 L2, 3 L1+L2.
+static int least_error_blocks(long long n) { return (int)std::min<long long>(512, (n + 1023) / 1024); }
+SC_API long long sc_least_error_workspace() { return 512 * (long long)sizeof(double); }
+SC_API int sc_least_error_fwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
+                              void* workspace, float* loss, hipStream_t stream) {
+  SC_CHECK_ARG(pred && tgt && len && workspace && loss && B >= 1 && T >= 1 && D >= 1, "sc_least_error_fwd: bad arguments");
+  SC_CHECK_ARG((dtype == 0 || dtype == 1) && loss_type >= 1 && loss_type <= 3, "sc_least_error_fwd: dtype 0 / 1, loss_type 1 .. 3");
+  const int nb = least_error_blocks((long long)B * T * D);
+  if (dtype == 0)
+    hipLaunchKernelGGL(least_error_partial_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)pred, tgt, len, B, T, D, loss_type,
+                       (double*)workspace);
+  else
+    hipLaunchKernelGGL(least_error_partial_kernel<unsigned short>, dim3(nb), dim3(256), 0, stream, (const unsigned short*)pred, tgt, len, B, T, D,
+                       loss_type, (double*)workspace);
+  SC_LAUNCH_CHECK("least_error_partial_kernel");
+  hipLaunchKernelGGL(least_error_finish_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, nb, len, B, T, D, normalized, loss);
+  SC_LAUNCH_CHECK("least_error_finish_kernel");
+  return SC_OK;
+}
+SC_API int sc_least_error_bwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
+                              const float* g, void* dpred, hipStream_t stream) {
+  SC_CHECK_ARG(pred && tgt && len && g && dpred && B >= 1 && T >= 1 && D >= 1, "sc_least_error_bwd: bad arguments");
+  SC_CHECK_ARG((dtype == 0 || dtype == 1) && loss_type >= 1 && loss_type <= 3, "sc_least_error_bwd: dtype 0 / 1, loss_type 1 .. 3");
+  const int nb = (int)std::min<long long>(2048, ((long long)B * T * D + 255) / 256);
+  if (dtype == 0)
+    hipLaunchKernelGGL(least_error_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)pred, tgt, len, B, T, D, loss_type, normalized, g,
+                       (float*)dpred);
+  else
+    hipLaunchKernelGGL(least_error_bwd_kernel<unsigned short>, dim3(nb), dim3(256), 0, stream, (const unsigned short*)pred, tgt, len, B, T, D,
+                       loss_type, normalized, g, (unsigned short*)dpred);
+  SC_LAUNCH_CHECK("least_error_bwd_kernel");
+  return SC_OK;
+}
+

@@ -1567,6 +1567,43 @@ def seq_loss(rows: torch.Tensor, text_len: torch.Tensor, length_normalized: bool
     return _SeqLoss.apply(rows, text_len, bool(length_normalized))
 
 
+class _LeastError(torch.autograd.Function):
+    """Masked L1 / L2 / L1+L2 of two (B, T, D) tracks over the frames t < len[b] as a scalar (sc_least_error_fwd / _bwd): two launches
+    forward, one backward, instead of ~10 torch launches each way (criterion/least_error.py)."""
+
+    _ws = {}
+
+    @staticmethod
+    def forward(ctx, pred, tgt, tgt_len, loss_type, normalized):
+        B, T, D = pred.shape
+        tl = tgt_len.to(device=pred.device, dtype=torch.int64).contiguous()
+        ws = _LeastError._ws.get(pred.device)
+        if ws is None:
+            ws = _LeastError._ws[pred.device] = torch.empty(lib.value("sc_least_error_workspace"), dtype=torch.uint8, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        lib.call("sc_least_error_fwd", dcode(pred), _p(pred), _p(tgt), _p(tl), B, T, D, loss_type, 1 if normalized else 0, _p(ws), _p(loss), stream())
+        ctx.save_for_backward(pred, tgt, tl)
+        ctx.meta = (loss_type, normalized)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt, tl = ctx.saved_tensors
+        loss_type, normalized = ctx.meta
+        B, T, D = pred.shape
+        g1 = g.float().reshape(1).contiguous()
+        dpred = torch.empty_like(pred)
+        lib.call("sc_least_error_bwd", dcode(pred), _p(pred), _p(tgt), _p(tl), B, T, D, loss_type, 1 if normalized else 0, _p(g1), _p(dpred), stream())
+        return dpred, None, None, None, None
+
+
+def least_error(pred: torch.Tensor, tgt: torch.Tensor, tgt_len: torch.Tensor, loss_type: str, normalized: bool) -> torch.Tensor:
+    """LeastError of pred (B, T, D) f32 / bf16, contiguous, against tgt (B, T, D) (no gradient) over the frames t < tgt_len[b]."""
+    require_gpu(pred, "least_error")
+    assert pred.dim() == 3 and pred.shape == tgt.shape and pred.is_contiguous() and not tgt.requires_grad
+    return _LeastError.apply(pred, tgt.detach().float().contiguous(), tgt_len, {"L1": 1, "L2": 2, "L1+L2": 3}[loss_type], bool(normalized))
+
+
 class _CTC(torch.autograd.Function):
     """Per-utterance CTC negative log-likelihood (B,) float32 with zero_infinity handling."""
 

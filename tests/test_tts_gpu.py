@@ -265,3 +265,43 @@ def test_pad_rows_through_the_c_abi(B, T, C, r):
     keep = torch.zeros(rows, dtype=torch.bool, device="cuda")
     keep[: B * (T + 2 * r)].view(B, T + 2 * r)[:, r: r + T] = True
     assert torch.equal(out2[keep], torch.full_like(out2[keep], 7.0)) and torch.equal(out2[~keep], torch.zeros_like(out2[~keep]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_type", ["L1", "L2", "L1+L2"])
+@pytest.mark.parametrize("normalized", [True, False])
+def test_fused_least_error_equals_the_elementwise_form(loss_type, normalized):
+    """LeastError through sc_least_error_fwd / _bwd (the GPU path of criterion/least_error.py) against the reference's sequence of
+    elementwise steps (least_error.py:96-129, run here on the same device through `update_range`-free torch arithmetic): value within
+    1e-6 relative, gradient within 1e-6 of its scale (f32) / bf16 rounding; ragged lengths, an empty utterance, D = 1 (pitch / energy / duration tracks) and D = 80 (mel)."""
+    from speechain_amd.criterion.least_error import LeastError
+    from speechain_amd.utilbox.train_util import make_mask_from_len
+
+    def reference(pred, tgt, tgt_len):
+        pred, tgt = pred.float(), tgt.float()
+        mask = make_mask_from_len(tgt_len, max_len=pred.size(1), return_3d=False)
+        d = pred - tgt
+        loss = {"L1": d.abs, "L2": lambda: d * d, "L1+L2": lambda: d.abs() + d * d}[loss_type]().mean(dim=-1)
+        loss = loss.masked_fill(~mask, 0.0)
+        return loss.sum() / mask.sum() if normalized else loss.sum(dim=-1).mean()
+
+    crit = LeastError(loss_type=loss_type, is_normalized=normalized)
+    gen = torch.Generator().manual_seed(3)
+    for (B, T, D), dtype in (((4, 37, 80), torch.float32), ((4, 37, 80), torch.bfloat16), ((5, 129, 1), torch.float32), ((3, 640, 80), torch.bfloat16)):
+        tgt = torch.randn(B, T, D, generator=gen).cuda()
+        lens = torch.randint(1, T + 1, (B,), generator=gen)
+        lens[0], lens[-1] = T, 0  # the whole track; empty
+        lens = lens.cuda()
+        p0 = (torch.randn(B, T, D, generator=gen).cuda() * 2).to(dtype)
+        p0[1, 2, 0] = tgt[1, 2, 0].to(dtype)  # (an exact zero difference where representable: |x|' = 0 there)
+        a = p0.clone().requires_grad_(True)
+        b = p0.clone().requires_grad_(True)
+        got = crit(pred=a if D > 1 else a.squeeze(-1), tgt=tgt if D > 1 else tgt.squeeze(-1), tgt_len=lens)
+        want = reference(b, tgt, lens)
+        assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)) + 1e-7, (float(got), float(want))
+        (got * 3.0).backward()
+        (want * 3.0).backward()
+        scale = float(b.grad.float().abs().max())
+        tol = (1e-6 if dtype == torch.float32 else 1e-2) * scale
+        assert float((a.grad.float() - b.grad.float()).abs().max()) <= tol, float((a.grad.float() - b.grad.float()).abs().max())
+        assert float(a.grad[-1].float().abs().max()) == 0.0  # the empty utterance
