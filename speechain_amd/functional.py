@@ -1791,6 +1791,14 @@ class _ConvFirst(torch.autograd.Function):
         return (None, dw.view_as(w), None if bn else dbeta, dgamma, dbeta if bn else None) + (None,) * 10
 
 
+def _conv1d_base(w: torch.Tensor):
+    """The nn.Conv1d parameter (out, in, k) behind an (out, in, k, 1) image-kernel view of it, or None."""
+    b = getattr(w, "_base", None)
+    if w.dim() == 4 and w.size(3) == 1 and b is not None and b.is_leaf and b.dim() == 3 and tuple(b.shape) == tuple(w.shape[:3]):
+        return b
+    return None
+
+
 class _ConvNext(torch.autograd.Function):
     """Conv2d(Cin, Cout, kernel, stride, padding) [+ BatchNorm2d] [+ activation] on a channels-last (B, Ti, Fi, Cin) image:
     im2col -> one GEMM against Wm[c_out][(kh, kw, c_in)] -> column statistics -> normalise + activation."""
@@ -1807,9 +1815,12 @@ class _ConvNext(torch.autograd.Function):
         g = (B, Ti, Fi, Cin, To, Fo, kh, kw, sh, sw, ph, pw)
         col = torch.empty(M, K, dtype=a.dtype, device=dev)
         lib.call("sc_im2col", code, _p(a), *g, _p(col), stream())
-        # (c_out, (kh, kw, c_in)) view of the weight in the compute dtype; cast here, not through the weight cache: the
-        # permuted copy is a new tensor every step
-        Wc = w.detach().permute(0, 2, 3, 1).reshape(Cout, K).to(a.dtype)
+        # (c_out, (kh, kw, c_in)) view of the weight in the compute dtype.  A Conv1d weight seen as an image kernel (the (out, in, k, 1)
+        # view the Conv1d postnet passes) has exactly the weight cache's Conv1d layout, column = tap * C + channel: its copies then come
+        # from the one refresh launch of the step instead of a permute + cast per block and direction.  Other kernels: cast here (the
+        # permuted copy is a new tensor every step).
+        base = _conv1d_base(w)
+        Wc = weights.fused([base], a.dtype) if base is not None else w.detach().permute(0, 2, 3, 1).reshape(Cout, K).to(a.dtype)
         bn = gamma is not None
         z = torch.empty(M, Cout, dtype=a.dtype, device=dev)
         gemm(code, _p(col), _p(Wc), _p(z), M, Cout, K, K, K, Cout, bias=bias.detach() if (bias is not None and not bn) else None)
@@ -1839,6 +1850,7 @@ class _ConvNext(torch.autograd.Function):
             y = z
         ctx.save_for_backward(col, z, w, scale, shift, mean, rstd)
         ctx.params = (w, bias, gamma, beta)
+        ctx.base = base
         ctx.meta = (g, act, slope, bn, bn and training)
         if not (bn and training and sync is not None):
             ctx.sync = None
@@ -1885,7 +1897,8 @@ class _ConvNext(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dcol = torch.empty(M, K, dtype=z.dtype, device=dev)
             if code == BF16:  # k-contiguous product against the transposed weight ((kh, kw, c_in), c_out)
-                Wt = w.detach().permute(2, 3, 1, 0).reshape(K, Cout).to(z.dtype)
+                Wt = (weights.fused_t([ctx.base], z.dtype) if ctx.base is not None
+                      else w.detach().permute(2, 3, 1, 0).reshape(K, Cout).to(z.dtype))
                 gemm(code, _p(dz), _p(Wt), _p(dcol), M, K, Cout, Cout, Cout, K)
             else:
                 Wm = w.detach().permute(0, 2, 3, 1).reshape(Cout, K)
