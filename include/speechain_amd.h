@@ -503,6 +503,10 @@ int sc_least_error_fwd(int dtype, const void* pred, const float* tgt, const long
                        void* workspace, float* loss, hipStream_t stream);
 int sc_least_error_bwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
                        const float* g, void* dpred, hipStream_t stream);
+/* out (1) f32 = sum_{b,t,d} a[b][t][d] * tab[t][d] for a (B, T, D) f32 / bf16 and tab (T, D) f32: the gradient of the scalar weight alpha of
+ * ScaledPositionalEncoding (speechain/module/transformer/pos_enc.py: x + alpha * table) from the gradient of the sum.  Deterministic.
+ * workspace: sc_least_error_workspace() bytes. */
+int sc_dot_table(int dtype, const void* a, const float* tab, int B, int T, int D, void* workspace, float* out, hipStream_t stream);
 
 /* lse[r] = logsumexp_v logits[r][v] */
 int sc_row_lse(int dtype, const void* logits, long long R, int V, long long ld, float* lse, hipStream_t stream);

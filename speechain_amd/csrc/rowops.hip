@@ -814,20 +814,51 @@ template <typename T>
 __global__ __launch_bounds__(256) void least_error_partial_kernel(const T* pred, const float* tgt, const long long* len, int B, int T_, int D,
                                                                   int loss_type, double* partial) {
   __shared__ double red[4];
-  const long long n = (long long)B * T_ * D, td = (long long)T_ * D;
   float acc = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
-    const int b = (int)(i / td);
-    const int t = (int)((i - (long long)b * td) / D);
-    if (t < len[b]) {
-      const float d = LeIo<T>::ld(pred, i) - tgt[i];
-      acc += loss_type == 1 ? fabsf(d) : loss_type == 2 ? d * d : fabsf(d) + d * d;
+  // frame by frame (one 32-bit quotient per frame, none per element); narrow tracks (D < 256: pitch, energy, duration) take the frames
+  // of a workgroup's pass side by side, 256 / D of them
+  const int fpp = D >= 256 ? 1 : 256 / D;  // frames per pass of the workgroup
+  for (int r0 = blockIdx.x * fpp; r0 < B * T_; r0 += gridDim.x * fpp) {
+    const int r = r0 + (D >= 256 ? 0 : (int)threadIdx.x / D);
+    const int d0 = D >= 256 ? (int)threadIdx.x : (int)threadIdx.x % D;
+    if (r < B * T_ && (D >= 256 || (int)threadIdx.x < fpp * D)) {
+      const int b = r / T_, t = r - b * T_;
+      if (t < len[b]) {
+        const long long base = (long long)r * D;
+        for (int dd = d0; dd < D; dd += 256) {
+          const float d = LeIo<T>::ld(pred, base + dd) - tgt[base + dd];
+          acc += loss_type == 1 ? fabsf(d) : loss_type == 2 ? d * d : fabsf(d) + d * d;
+        }
+      }
     }
   }
   const double w = (double)sc_wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// sum_{b,t,d} a[b][t][d] * tab[t][d]: the gradient of the scalar weight of ScaledPositionalEncoding (speechain/module/transformer/pos_enc.py:
+// alpha * table added to the input) from the gradient of the sum -- a cast, a broadcast product and a sum in torch (42 us per site).
+template <typename T>
+__global__ __launch_bounds__(256) void dot_table_partial_kernel(const T* a, const float* tab, int B, int T_, int D, double* partial) {
+  __shared__ double red[4];
+  float acc = 0.f;
+  for (int r = blockIdx.x; r < B * T_; r += gridDim.x) {  // (row by row: one 32-bit remainder per row, none per element)
+    const long long ra = (long long)r * D, rt = (long long)(r % T_) * D;
+    for (int d = threadIdx.x; d < D; d += 256) acc = fmaf(LeIo<T>::ld(a, ra + d), tab[rt + d], acc);
+  }
+  const double w = (double)sc_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void sum_partials_to_float_kernel(const double* partial, int np, float* out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < np; ++i) s += partial[i];
+    out[0] = (float)s;
+  }
 }
 
 // denominator shared by both directions: D x (number of valid frames, or B)
@@ -854,17 +885,24 @@ __global__ __launch_bounds__(256) void least_error_bwd_kernel(const T* pred, con
   if (threadIdx.x == 0) s_scale = (float)((double)g[0] / least_error_denominator(len, B, T_, D, normalized));
   __syncthreads();
   const float scale = s_scale;
-  const long long n = (long long)B * T_ * D, td = (long long)T_ * D;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
-    const int b = (int)(i / td);
-    const int t = (int)((i - (long long)b * td) / D);
-    float v = 0.f;
-    if (t < len[b]) {
-      const float d = LeIo<T>::ld(pred, i) - tgt[i];
-      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // (torch: the gradient of |x| at 0 is 0)
-      v = scale * (loss_type == 1 ? sg : loss_type == 2 ? 2.f * d : sg + 2.f * d);
+  const int fpp = D >= 256 ? 1 : 256 / D;
+  for (int r0 = blockIdx.x * fpp; r0 < B * T_; r0 += gridDim.x * fpp) {
+    const int r = r0 + (D >= 256 ? 0 : (int)threadIdx.x / D);
+    const int d0 = D >= 256 ? (int)threadIdx.x : (int)threadIdx.x % D;
+    if (r < B * T_ && (D >= 256 || (int)threadIdx.x < fpp * D)) {
+      const int b = r / T_, t = r - b * T_;
+      const bool valid = t < len[b];
+      const long long base = (long long)r * D;
+      for (int dd = d0; dd < D; dd += 256) {
+        float v = 0.f;
+        if (valid) {
+          const float d = LeIo<T>::ld(pred, base + dd) - tgt[base + dd];
+          const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // (torch: the gradient of |x| at 0 is 0)
+          v = scale * (loss_type == 1 ? sg : loss_type == 2 ? 2.f * d : sg + 2.f * d);
+        }
+        LeIo<T>::st(dpred, base + dd, v);
+      }
     }
-    LeIo<T>::st(dpred, i, v);
   }
 }
 
@@ -1119,13 +1157,13 @@ SC_API int sc_seq_loss_bwd(const float* g, const long long* len, int B, int L, i
 // LeastError (speechain/criterion/least_error.py:96-129) of pred (B, T, D) f32 / bf16 against tgt (B, T, D) f32 over the frames t < len[b]:
 // loss (1) f32 = sum_valid mean_d f(pred - tgt) / (valid frames | B); workspace: sc_least_error_workspace() bytes.  _bwd: dpred (B, T, D) in
 // pred's dtype for an upstream scalar g (device), zero at the frames past the lengths.  dtype 0 = f32, 1 = bf16; loss_type 1 L1, 2 L2, 3 L1+L2.
-static int least_error_blocks(long long n) { return (int)std::min<long long>(512, (n + 1023) / 1024); }
+static int least_error_blocks(long long frames, int D) { const int fpp = D >= 256 ? 1 : 256 / D; return (int)std::min<long long>(512, (frames + fpp - 1) / fpp); }
 SC_API long long sc_least_error_workspace() { return 512 * (long long)sizeof(double); }
 SC_API int sc_least_error_fwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
                               void* workspace, float* loss, hipStream_t stream) {
-  SC_CHECK_ARG(pred && tgt && len && workspace && loss && B >= 1 && T >= 1 && D >= 1, "sc_least_error_fwd: bad arguments");
+  SC_CHECK_ARG(pred && tgt && len && workspace && loss && B >= 1 && T >= 1 && D >= 1 && (long long)B * T <= 0x3fffffffLL, "sc_least_error_fwd: bad arguments");
   SC_CHECK_ARG((dtype == 0 || dtype == 1) && loss_type >= 1 && loss_type <= 3, "sc_least_error_fwd: dtype 0 / 1, loss_type 1 .. 3");
-  const int nb = least_error_blocks((long long)B * T * D);
+  const int nb = least_error_blocks((long long)B * T, D);
   if (dtype == 0)
     hipLaunchKernelGGL(least_error_partial_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)pred, tgt, len, B, T, D, loss_type,
                        (double*)workspace);
@@ -1137,11 +1175,28 @@ SC_API int sc_least_error_fwd(int dtype, const void* pred, const float* tgt, con
   SC_LAUNCH_CHECK("least_error_finish_kernel");
   return SC_OK;
 }
+// out (1) f32 = sum over (b, t, d) of a (B, T, D) f32 / bf16 times tab (T, D) f32 (deterministic: fixed partial order); workspace:
+// sc_least_error_workspace() bytes.
+SC_API int sc_dot_table(int dtype, const void* a, const float* tab, int B, int T, int D, void* workspace, float* out, hipStream_t stream) {
+  SC_CHECK_ARG(a && tab && workspace && out && B >= 1 && T >= 1 && D >= 1 && (dtype == 0 || dtype == 1) && (long long)B * T <= 0x7fffffffLL,
+               "sc_dot_table: bad arguments");
+  const int nb = (int)std::min<long long>(512, (long long)B * T);
+  if (dtype == 0)
+    hipLaunchKernelGGL(dot_table_partial_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)a, tab, B, T, D, (double*)workspace);
+  else
+    hipLaunchKernelGGL(dot_table_partial_kernel<unsigned short>, dim3(nb), dim3(256), 0, stream, (const unsigned short*)a, tab, B, T, D,
+                       (double*)workspace);
+  SC_LAUNCH_CHECK("dot_table_partial_kernel");
+  hipLaunchKernelGGL(sum_partials_to_float_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, nb, out);
+  SC_LAUNCH_CHECK("sum_partials_to_float_kernel");
+  return SC_OK;
+}
 SC_API int sc_least_error_bwd(int dtype, const void* pred, const float* tgt, const long long* len, int B, int T, int D, int loss_type, int normalized,
                               const float* g, void* dpred, hipStream_t stream) {
-  SC_CHECK_ARG(pred && tgt && len && g && dpred && B >= 1 && T >= 1 && D >= 1, "sc_least_error_bwd: bad arguments");
+  SC_CHECK_ARG(pred && tgt && len && g && dpred && B >= 1 && T >= 1 && D >= 1 && (long long)B * T <= 0x3fffffffLL, "sc_least_error_bwd: bad arguments");
   SC_CHECK_ARG((dtype == 0 || dtype == 1) && loss_type >= 1 && loss_type <= 3, "sc_least_error_bwd: dtype 0 / 1, loss_type 1 .. 3");
-  const int nb = (int)std::min<long long>(2048, ((long long)B * T * D + 255) / 256);
+  const int fpp = D >= 256 ? 1 : 256 / D;
+  const int nb = (int)std::min<long long>(4096, ((long long)B * T + fpp - 1) / fpp);
   if (dtype == 0)
     hipLaunchKernelGGL(least_error_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)pred, tgt, len, B, T, D, loss_type, normalized, g,
                        (float*)dpred);

@@ -1463,7 +1463,12 @@ def attention_core(q_buf, kv_buf, iq, ik, iv, num_heads, d_model, mask, causal, 
 # Positional encoding add
 # ---------------------------------------------------------------------------------------------------------------------
 
+_POSENC_DOT = _os.environ.get("SC_POSENC_DOT", "1") == "1"
+
+
 class _PosEnc(torch.autograd.Function):
+    _ws = {}
+
     @staticmethod
     def forward(ctx, x, table, alpha, xscale, drop_p):
         require_gpu(x, "positional encoding")
@@ -1487,7 +1492,17 @@ class _PosEnc(torch.autograd.Function):
         dalpha = None
         if has_alpha:
             (tab,) = ctx.saved_tensors
-            dalpha = (dz.float() * tab[:T]).sum()  # scalar parameter of the TTS recipes: a device-side reduction
+            # scalar parameter of the TTS recipes: one fused reduction (sc_dot_table) instead of a cast, a broadcast product and a sum
+            if not _POSENC_DOT:  # (A/B knob SC_POSENC_DOT=0: the torch form)
+                return (dz if xscale == 1.0 else dz * xscale), None, (dz.float() * tab[:T]).sum(), None, None
+            B = dz.numel() // (T * D)
+            ws = _PosEnc._ws.get(dz.device)
+            if ws is None:
+                ws = _PosEnc._ws[dz.device] = torch.empty(lib.value("sc_least_error_workspace"), dtype=torch.uint8, device=dz.device)
+            dalpha = torch.empty(1, dtype=torch.float32, device=dz.device)
+            tabc = tab[:T].float().contiguous()
+            lib.call("sc_dot_table", dcode(dz), _p(dz), _p(tabc), B, T, D, _p(ws), _p(dalpha), stream())
+            dalpha = dalpha.reshape(())
         if xscale != 1.0:
             dx = torch.empty_like(dz)
             lib.call("sc_dropout", dcode(dz), _p(dz), _p(dx), dz.numel(), float(xscale), 0.0, 0, 0, stream())

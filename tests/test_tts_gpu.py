@@ -305,3 +305,21 @@ def test_fused_least_error_equals_the_elementwise_form(loss_type, normalized):
         tol = (1e-6 if dtype == torch.float32 else 1e-2) * scale
         assert float((a.grad.float() - b.grad.float()).abs().max()) <= tol, float((a.grad.float() - b.grad.float()).abs().max())
         assert float(a.grad[-1].float().abs().max()) == 0.0  # the empty utterance
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_positional_encoding_scale_gradient(dtype):
+    """The gradient of ScaledPositionalEncoding's scalar alpha (pos_enc.py: x + alpha * table) through sc_dot_table against the torch
+    form sum(dy * table) -- (B, T, D) with T not a multiple of anything and D = 384 (the FastSpeech2 width) and 20."""
+    gen = torch.Generator().manual_seed(11)
+    for B, T, D in ((3, 37, 384), (2, 50, 20)):
+        table = torch.randn(1, 64, D, generator=gen).cuda()
+        x = torch.randn(B, T, D, generator=gen).cuda().to(dtype).requires_grad_(True)
+        alpha = torch.nn.Parameter(torch.tensor(0.7).cuda())
+        w = torch.randn(B, T, D, generator=gen).cuda().to(dtype)
+        y = Fn.posenc_add(x, table[:, :T], alpha, 1.0, 0.0)
+        (y.float() * w.float()).sum().backward()
+        want = (w.float() * table[0, :T]).sum()
+        assert abs(float(alpha.grad) - float(want)) <= (1e-5 if dtype == torch.float32 else 2e-2) * (abs(float(want)) + 1.0), (float(alpha.grad), float(want))
+        assert torch.allclose(x.grad.float(), w.float(), atol=1e-6 if dtype == torch.float32 else 1e-2)
