@@ -774,7 +774,8 @@ class ASRDecodeWorkload:
         mfma = fast and V % 4 == 0  # (exact-f32 matrix-core products, the 16 rows of a beam = one tile)
         return {"bound": "hbm", "kernel": "ctc_psi_mfma_kernel" if mfma else "ctc_psi_fast_kernel" if fast else "ctc_psi_kernel",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("ctc_psi_mfma_kernel<true>") if mfma else None,
+                "kernel_ms": round(per, 5), "algorithmic_bytes": alg,
                 "note": (f"{rate:.2f} T multiply-adds/s: one per (row, token, frame), the exponential's second factor made once per batch; "
                          if fast else f"{rate:.2f} T exp/s: one v_exp per (row, token, frame); ") + "launches per batch "
                         + ", ".join(f"{k} {c} x {t / max(c, 1) * 1e3:.1f} us" for k, (c, t) in self.kernel_ms.items() if c)}
@@ -828,7 +829,7 @@ def cpu_baseline_decode(seconds: float):
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` as measured by the committed PMC passes (None when there is no such record)."""
-    for name in ("r03_frontend_pmc_traffic.json", "r03_train_step_pmc_traffic.json", "r02_frontend_pmc_traffic.json", "r02_train_step_pmc_traffic.json",
+    for name in ("r03_frontend_pmc_traffic.json", "r03_train_step_pmc_traffic.json", "r03_decode_pmc_traffic.json", "r02_frontend_pmc_traffic.json", "r02_train_step_pmc_traffic.json",
                  "r01_frontend_pmc_traffic.json", "r01_train_step_pmc_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
